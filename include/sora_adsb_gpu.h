@@ -1,0 +1,197 @@
+/*
+ * sora_adsb_gpu.h -- C ABI of libsora_adsb_gpu.so, the MI355X (gfx950)
+ * implementation of Sora's ADS-B receive chain.
+ *
+ * The reference has no plugin / FFI layer: its seams
+ * are the plain C functions of src/ads-b/plane-iq.h:10-13 (demodulator
+ * iterator), src/ads-b/plane.h:16-17 (validator) and
+ * src/ads-b/planes-main-loop.h:6-9 (mode entry).  Those keep their names and
+ * signatures in include/sora_adsb_host.h; this header is the thin layer
+ * underneath them that hands large IQ buffers to the HIP kernels.  Plain
+ * pointers, sizes and integer return codes only: no exceptions and no abort()
+ * cross this boundary (the reference aborts on allocation failure,
+ * src/util/exception.c:58-59; this library returns SORA_ERR_NOMEM instead).
+ *
+ * One context per device and per stream of samples; a context is used from
+ * one host thread at a time.
+ *
+ * What a context computes, per position p of a chunk (all of it a pure
+ * function of samples p .. p+239, reference src/ads-b/plane-iq.c:121-194):
+ *   magnitude m = I^2 + Q^2                      plane-iq.c:131-136
+ *   candidate iff the 8-comparison predicate     plane-iq.c:173-175
+ *   112 PPM bits, bit_k = m[p+17+2k] <= m[p+16+2k]   plane-iq.c:58-86
+ *   amplitude_56 = sum_{k<56} (m[p+16+2k]+m[p+17+2k])/2   plane-iq.c:62-73
+ *   DF, CRC-24 syndrome, address                 plane.c:457-484
+ * and then the one stateful rule: a DF11/17/18 frame
+ * is accepted iff its syndrome is 0; any other DF iff an accepted DF11/17/18
+ * frame with the same address starts at a smaller position.
+ */
+#ifndef SORA_ADSB_GPU_H_
+#define SORA_ADSB_GPU_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SORA_OK			0
+#define SORA_ERR_INVALID	(-1)	/* bad argument */
+#define SORA_ERR_NO_DEVICE	(-2)	/* no usable gfx950 device */
+#define SORA_ERR_HIP		(-3)	/* a HIP call failed: sora_adsb_last_error() */
+#define SORA_ERR_OVERFLOW	(-4)	/* a device list was too small; see sora_adsb_get_counts */
+#define SORA_ERR_NOMEM		(-5)
+#define SORA_ERR_ALIGN		(-6)	/* device pointer not 16-byte aligned */
+#define SORA_ERR_STATE		(-7)	/* call out of order */
+
+/* encodings: the numbers of reference src/radio/radio-file.h:6-12 */
+#define SORA_ENC_UC8	1
+#define SORA_ENC_SC16	2
+#define SORA_ENC_SC8	3
+
+#define SORA_ADSB_WINDOW	240	/* samples a candidate reads */
+#define SORA_ADSB_HALO		239	/* samples past the last owned position */
+#define SORA_ADSB_MSG_BITS	112
+
+/* emit modes */
+#define SORA_EMIT_ACCEPTED	0	/* frames plane_set_parse_message() accepts
+					 * (what planes_main_loop prints) */
+#define SORA_EMIT_CANDIDATES	1	/* every candidate plane_iq_get_next()
+					 * yields, accepted or not (parity mode) */
+
+/* frame flags */
+#define SORA_FRAME_LONG		0x01	/* 16 <= DF <= 24, plane.c:462 */
+#define SORA_FRAME_SQUITTER	0x02	/* DF 11, 17, 18, plane.c:473 */
+#define SORA_FRAME_ACCEPTED	0x04
+
+/* 48 bytes, what the demodulator + validator know about one frame */
+struct sora_adsb_frame {
+    uint64_t position;	   /* in_flight_msg.position, plane-iq.c:47 (global) */
+    uint32_t bits[4];	   /* 112 bits MSB first (bit k = bits[k/32]>>(31-k%32));
+			    * all 112 are sliced even for short frames
+			    * (SURVEY.md D2); low 16 bits of bits[3] are 0 */
+    double amplitude_56;   /* plane-iq.c:72-73; amplitude = this / 56 (:189) */
+    uint32_t syndrome;	   /* crc ^ ap, plane.c:472-475 / :480 */
+    uint32_t address;	   /* bits[8,32) for squitters, crc ^ ap otherwise */
+    uint32_t sum56;	   /* 8-bit encodings: integer sum over k<56 of
+			    * M[p+16+2k]+M[p+17+2k], M = I^2+Q^2 in counts;
+			    * amplitude_56 == sum56 * 2^-15 exactly.  0 for sc16 */
+    uint8_t df;		   /* bits[0,5) */
+    int8_t corrected_bit;  /* -1: none (the reference never corrects, D3) */
+    uint8_t flags;	   /* SORA_FRAME_* */
+    uint8_t reserved;
+};
+
+struct sora_adsb_config {
+    uint64_t max_chunk_samples;	/* largest chunk a scan will be given */
+    uint64_t max_candidates;	/* device list sizes; 0 = max_chunk_samples/16 */
+    uint64_t max_squitters;	/* 0 = max_chunk_samples/256 + 4096 */
+    uint64_t max_frames;	/* 0 = max_squitters (EMIT_ACCEPTED) or
+				 * max_candidates (EMIT_CANDIDATES) */
+    int32_t emit_mode;		/* SORA_EMIT_* */
+    int32_t reserved;
+    void *stream;		/* hipStream_t to run on; NULL = own stream */
+};
+
+struct sora_adsb_counts {	/* of the last scan / resolve */
+    uint64_t positions;		/* positions scanned */
+    uint64_t candidates;	/* predicate hits (plane_iq_get_next yields) */
+    uint64_t squitters;		/* clean DF11/17/18 */
+    uint64_t dirty_squitters;	/* DF11/17/18 with a non-zero syndrome */
+    uint64_t replies;		/* candidates of every other DF */
+    uint64_t frames;		/* frames sora_adsb_collect will return */
+};
+
+typedef struct sora_adsb_ctx sora_adsb_ctx;
+
+/* Library / device queries.  No GPU needed for the first two. */
+const char *sora_adsb_version(void);
+const char *sora_adsb_strerror(int code);
+int sora_adsb_device_count(void);
+
+int sora_adsb_create(sora_adsb_ctx **out, int device,
+	const struct sora_adsb_config *cfg);
+void sora_adsb_destroy(sora_adsb_ctx *ctx);
+const char *sora_adsb_last_error(const sora_adsb_ctx *ctx);
+
+/* Forget every known address (a new, unrelated capture). */
+int sora_adsb_reset(sora_adsb_ctx *ctx);
+
+/*
+ * Stage 1 -- the fused scan kernel, asynchronous on the context's stream.
+ * d_iq: DEVICE pointer (16-byte aligned) to `nbytes` bytes of interleaved IQ;
+ * a trailing partial sample is dropped (plane-iq.c:131, :138).  Positions
+ * 0 .. n_owned-1 of the chunk are scanned, and of those only p with
+ * p + 240 <= n_samples (plane-iq.c:148-166): a middle shard
+ * passes its owned count and carries 239 halo samples behind it, the last
+ * shard passes n_owned = n_samples.  base_position is the global index of
+ * the chunk's first sample.
+ */
+int sora_adsb_scan(sora_adsb_ctx *ctx, const void *d_iq, size_t nbytes,
+	int encoding, uint64_t base_position, uint64_t n_owned);
+
+/*
+ * Exchange step for time-sharded captures: the clean
+ * squitters of the last scan as 8-byte records (position << 24 | address),
+ * copied to a DEVICE buffer the caller owns, and records of other shards
+ * merged into this context's first-seen table.  Both asynchronous.
+ */
+int sora_adsb_squitter_count(sora_adsb_ctx *ctx, uint64_t *n); /* syncs */
+int sora_adsb_copy_squitters(sora_adsb_ctx *ctx, void *d_dst, size_t cap_records);
+int sora_adsb_add_known(sora_adsb_ctx *ctx, const void *d_records,
+	size_t n_records);
+
+/*
+ * Stage 2 -- merges this scan's squitters into the first-seen table, filters
+ * the replies against it, sorts the accepted positions and re-slices them
+ * into frames (bits, amplitude, syndrome).  Asynchronous.
+ */
+int sora_adsb_resolve(sora_adsb_ctx *ctx);
+
+/* scan + resolve on a device buffer */
+int sora_adsb_submit_device(sora_adsb_ctx *ctx, const void *d_iq, size_t nbytes,
+	int encoding, uint64_t base_position, uint64_t n_owned);
+/* same from host memory: staged through the context's device buffer */
+int sora_adsb_submit_host(sora_adsb_ctx *ctx, const void *h_iq, size_t nbytes,
+	int encoding, uint64_t base_position, uint64_t n_owned);
+
+/*
+ * Waits for the stream, then copies the frames of the last resolve, in
+ * increasing position, to host memory (sora_adsb_collect) or to a device
+ * buffer (sora_adsb_collect_device).  *n is the number available; at most
+ * cap are written.  Returns SORA_ERR_OVERFLOW if a device list overflowed
+ * during the scan (sora_adsb_get_counts then tells the sizes that were needed).
+ */
+int sora_adsb_collect(sora_adsb_ctx *ctx, struct sora_adsb_frame *out,
+	size_t cap, size_t *n);
+int sora_adsb_collect_device(sora_adsb_ctx *ctx, void *d_out, size_t cap,
+	size_t *n);
+
+int sora_adsb_get_counts(sora_adsb_ctx *ctx, struct sora_adsb_counts *out); /* syncs */
+int sora_adsb_synchronize(sora_adsb_ctx *ctx);
+
+/* Duration of the last scan kernel alone, HIP events on the context's
+ * stream, in milliseconds (syncs). */
+int sora_adsb_last_scan_ms(sora_adsb_ctx *ctx, float *ms);
+
+/*
+ * Magnitudes only (row a1), for the 1-ulp check north_star asks for:
+ * m[i] as float for every sample, DEVICE in, DEVICE out.
+ */
+int sora_adsb_magnitude(sora_adsb_ctx *ctx, const void *d_iq, size_t nbytes,
+	int encoding, float *d_m);
+
+/* Device memory helpers so that C callers need no HIP headers. */
+int sora_adsb_device_alloc(int device, size_t nbytes, void **d_ptr);
+int sora_adsb_device_free(int device, void *d_ptr);
+int sora_adsb_copy_to_device(int device, void *d_dst, const void *h_src,
+	size_t nbytes);
+int sora_adsb_copy_to_host(int device, void *h_dst, const void *d_src,
+	size_t nbytes);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* SORA_ADSB_GPU_H_ */

@@ -1,0 +1,594 @@
+/*
+ * adsb_gpu.hip -- the C ABI of include/sora_adsb_gpu.h: contexts, device
+ * buffers and the launch sequence around the kernels of adsb_kernels.hip.
+ * Host code only; every error becomes an integer code (no exceptions, no
+ * abort: SURVEY.md section 8b).
+ */
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/sora_adsb_gpu.h"
+#include "adsb_kernels.h"
+#include "adsb_tile.h"
+
+#define SORA_ADDRESSES	(1u << 24)
+
+struct sora_adsb_ctx {
+    int device;
+    hipStream_t stream;
+    bool own_stream;
+    hipEvent_t ev_scan_begin, ev_scan_end;
+    bool scan_timed;
+
+    sora_adsb_config cfg;
+    uint32_t max_groups;	/* workgroups the scan kernel may use */
+    uint64_t rec_total, sq_total, acc_total, frames_cap;
+
+    /* device */
+    uint64_t *d_rec, *d_sq, *d_acc, *d_first_seen, *d_stats;
+    uint64_t *d_acc_offset, *d_sq_offset;
+    uint32_t *d_rec_count, *d_sq_count, *d_acc_count;
+    sora_adsb_frame *d_frames;
+    uint8_t *d_stage;
+    size_t stage_bytes;
+
+    /* host mirrors */
+    uint32_t *h_counts;		/* 3 * max_groups */
+    uint64_t *h_stats;		/* max_groups * SORA_STAT_WORDS */
+    uint64_t h_total[2];
+
+    /* the chunk in flight */
+    bool scanned, resolved;
+    sora_scan_args scan;
+    sora_resolve_args res;
+    uint32_t groups;
+
+    char err[256];
+};
+
+namespace {
+
+int
+fail(sora_adsb_ctx *ctx, int code, const char *fmt, ...) {
+    if (ctx != nullptr) {
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(ctx->err, sizeof ctx->err, fmt, ap);
+	va_end(ap);
+    }
+    return code;
+}
+
+#define HIP_TRY(ctx, call) do { \
+	hipError_t e_ = (call); \
+	if (e_ != hipSuccess) \
+	    return fail((ctx), SORA_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+int
+bytes_per_sample(int encoding) {
+    switch (encoding) {
+    case SORA_ENC_UC8:
+    case SORA_ENC_SC8:
+	return 2;
+    case SORA_ENC_SC16:
+	return 4;
+    default:
+	return 0;
+    }
+}
+
+template <typename T> hipError_t
+dev_alloc(T **p, uint64_t n) {
+    return hipMalloc(reinterpret_cast<void **>(p), (n > 0? n : 1) * sizeof(T));
+}
+
+} /* namespace */
+
+extern "C" const char *
+sora_adsb_version(void) {
+    return "sora_adsb_gpu 0.1 (gfx950)";
+}
+
+extern "C" const char *
+sora_adsb_strerror(int code) {
+    switch (code) {
+    case SORA_OK: return "ok";
+    case SORA_ERR_INVALID: return "invalid argument";
+    case SORA_ERR_NO_DEVICE: return "no usable HIP device";
+    case SORA_ERR_HIP: return "HIP call failed";
+    case SORA_ERR_OVERFLOW: return "device list overflow";
+    case SORA_ERR_NOMEM: return "out of memory";
+    case SORA_ERR_ALIGN: return "device pointer not 16-byte aligned";
+    case SORA_ERR_STATE: return "call out of order";
+    default: return "unknown error";
+    }
+}
+
+extern "C" int
+sora_adsb_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess)
+	return 0;
+    return n;
+}
+
+extern "C" const char *
+sora_adsb_last_error(const sora_adsb_ctx *ctx) {
+    return ctx != nullptr? ctx->err : "";
+}
+
+extern "C" void
+sora_adsb_destroy(sora_adsb_ctx *ctx) {
+    if (ctx == nullptr)
+	return;
+    (void) hipSetDevice(ctx->device);
+    if (ctx->stream != nullptr)
+	(void) hipStreamSynchronize(ctx->stream);
+    (void) hipFree(ctx->d_rec);
+    (void) hipFree(ctx->d_sq);
+    (void) hipFree(ctx->d_acc);
+    (void) hipFree(ctx->d_first_seen);
+    (void) hipFree(ctx->d_stats);
+    (void) hipFree(ctx->d_acc_offset);
+    (void) hipFree(ctx->d_sq_offset);
+    (void) hipFree(ctx->d_rec_count);
+    (void) hipFree(ctx->d_sq_count);
+    (void) hipFree(ctx->d_acc_count);
+    (void) hipFree(ctx->d_frames);
+    (void) hipFree(ctx->d_stage);
+    if (ctx->h_counts != nullptr)
+	(void) hipHostFree(ctx->h_counts);
+    if (ctx->h_stats != nullptr)
+	(void) hipHostFree(ctx->h_stats);
+    if (ctx->ev_scan_begin != nullptr)
+	(void) hipEventDestroy(ctx->ev_scan_begin);
+    if (ctx->ev_scan_end != nullptr)
+	(void) hipEventDestroy(ctx->ev_scan_end);
+    if (ctx->own_stream && ctx->stream != nullptr)
+	(void) hipStreamDestroy(ctx->stream);
+    free(ctx);
+}
+
+extern "C" int
+sora_adsb_reset(sora_adsb_ctx *ctx) {
+    if (ctx == nullptr)
+	return SORA_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, sora_launch_fill_u64(ctx->d_first_seen, ~0ull, SORA_ADDRESSES,
+	    ctx->stream));
+    ctx->scanned = ctx->resolved = false;
+    return SORA_OK;
+}
+
+extern "C" int
+sora_adsb_create(sora_adsb_ctx **out, int device, const sora_adsb_config *cfg) {
+    int ndev = 0;
+    hipDeviceProp_t prop;
+
+    if (out == nullptr || cfg == nullptr || cfg->max_chunk_samples == 0)
+	return SORA_ERR_INVALID;
+    *out = nullptr;
+    if (cfg->emit_mode != SORA_EMIT_ACCEPTED && cfg->emit_mode != SORA_EMIT_CANDIDATES)
+	return SORA_ERR_INVALID;
+    if (cfg->max_chunk_samples >= (1ull << SORA_REC_POS_BITS))
+	return SORA_ERR_INVALID;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+	return SORA_ERR_NO_DEVICE;
+    if (device < 0 || device >= ndev)
+	return SORA_ERR_NO_DEVICE;
+
+    sora_adsb_ctx *ctx = static_cast<sora_adsb_ctx *>(calloc(1, sizeof *ctx));
+    if (ctx == nullptr)
+	return SORA_ERR_NOMEM;
+    ctx->device = device;
+    ctx->cfg = *cfg;
+    *out = ctx;			/* so the caller can read last_error and destroy */
+
+    HIP_TRY(ctx, hipSetDevice(device));
+    HIP_TRY(ctx, hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+	return fail(ctx, SORA_ERR_NO_DEVICE,
+		"device %d is %s: this library holds gfx950 code only", device,
+		prop.gcnArchName);
+
+    if (cfg->stream != nullptr) {
+	ctx->stream = static_cast<hipStream_t>(cfg->stream);
+    } else {
+	HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamDefault));
+	ctx->own_stream = true;
+    }
+    HIP_TRY(ctx, hipEventCreate(&ctx->ev_scan_begin));
+    HIP_TRY(ctx, hipEventCreate(&ctx->ev_scan_end));
+
+    /* three 41 KB workgroups fit the 160 KB of LDS of a CU */
+    ctx->max_groups = (uint32_t) prop.multiProcessorCount * 3;
+    if (ctx->max_groups == 0)
+	ctx->max_groups = 1;
+
+    const uint64_t n = cfg->max_chunk_samples;
+    ctx->rec_total = cfg->max_candidates != 0? cfg->max_candidates : n / 16 + 65536;
+    ctx->sq_total = cfg->max_squitters != 0? cfg->max_squitters : n / 256 + 65536;
+    ctx->acc_total = cfg->max_frames != 0? cfg->max_frames :
+	    cfg->emit_mode == SORA_EMIT_CANDIDATES? ctx->rec_total : ctx->sq_total;
+    ctx->frames_cap = ctx->acc_total;
+
+    const uint32_t g = ctx->max_groups;
+    if (dev_alloc(&ctx->d_rec, ctx->rec_total) != hipSuccess ||
+	    dev_alloc(&ctx->d_sq, ctx->sq_total) != hipSuccess ||
+	    dev_alloc(&ctx->d_acc, ctx->acc_total) != hipSuccess ||
+	    dev_alloc(&ctx->d_frames, ctx->frames_cap) != hipSuccess ||
+	    dev_alloc(&ctx->d_first_seen, SORA_ADDRESSES) != hipSuccess ||
+	    dev_alloc(&ctx->d_stats, (uint64_t) g * SORA_STAT_WORDS) != hipSuccess ||
+	    dev_alloc(&ctx->d_acc_offset, g + 1) != hipSuccess ||
+	    dev_alloc(&ctx->d_sq_offset, g + 1) != hipSuccess ||
+	    dev_alloc(&ctx->d_rec_count, g) != hipSuccess ||
+	    dev_alloc(&ctx->d_sq_count, g) != hipSuccess ||
+	    dev_alloc(&ctx->d_acc_count, g) != hipSuccess)
+	return fail(ctx, SORA_ERR_NOMEM, "hipMalloc of the device lists failed");
+    HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_counts),
+	    3 * (size_t) g * sizeof(uint32_t), hipHostMallocDefault));
+    HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_stats),
+	    (size_t) g * SORA_STAT_WORDS * sizeof(uint64_t), hipHostMallocDefault));
+
+    int rc = sora_adsb_reset(ctx);
+    if (rc != SORA_OK)
+	return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return SORA_OK;
+}
+
+extern "C" int
+sora_adsb_scan(sora_adsb_ctx *ctx, const void *d_iq, size_t nbytes, int encoding,
+	uint64_t base_position, uint64_t n_owned) {
+    if (ctx == nullptr)
+	return SORA_ERR_INVALID;
+    const int bps = bytes_per_sample(encoding);
+    if (bps == 0)
+	return fail(ctx, SORA_ERR_INVALID, "unknown encoding %d", encoding);
+    if (encoding == SORA_ENC_SC16)
+	return fail(ctx, SORA_ERR_INVALID,
+		"sc16 scan is not built yet (SURVEY.md section 8f.2)");
+    if (d_iq == nullptr && nbytes != 0)
+	return fail(ctx, SORA_ERR_INVALID, "null IQ pointer");
+    if ((reinterpret_cast<uintptr_t>(d_iq) & 15) != 0)
+	return fail(ctx, SORA_ERR_ALIGN, "IQ pointer %p is not 16-byte aligned", d_iq);
+    const uint64_t n_samples = nbytes / (size_t) bps;
+    if (n_samples > ctx->cfg.max_chunk_samples)
+	return fail(ctx, SORA_ERR_INVALID,
+		"chunk of %llu samples exceeds max_chunk_samples %llu",
+		(unsigned long long) n_samples,
+		(unsigned long long) ctx->cfg.max_chunk_samples);
+    if (base_position + n_samples >= (1ull << 40))
+	return fail(ctx, SORA_ERR_INVALID, "positions beyond 2^40 are not supported");
+
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+
+    /* positions p < n_owned with p + 240 <= n_samples (plane-iq.c:148-166) */
+    uint64_t n_scan = n_samples >= SORA_ADSB_WINDOW? n_samples - SORA_ADSB_HALO : 0;
+    if (n_owned < n_scan)
+	n_scan = n_owned;
+    const uint64_t n_tiles = sora_scan_tiles(n_scan, encoding);
+    uint32_t groups = ctx->max_groups;
+    if (n_tiles < groups)
+	groups = n_tiles > 0? (uint32_t) n_tiles : 1;
+
+    sora_scan_args &a = ctx->scan;
+    memset(&a, 0, sizeof a);
+    a.iq = static_cast<const uint8_t *>(d_iq);
+    a.n_samples = n_samples;
+    a.n_scan = n_scan;
+    a.n_tiles = n_tiles;
+    a.encoding = encoding;
+    a.emit_all = ctx->cfg.emit_mode == SORA_EMIT_CANDIDATES;
+    a.rec = ctx->d_rec;
+    a.sq = ctx->d_sq;
+    a.rec_cap = (uint32_t) (ctx->rec_total / groups > 0x7fffffffull?
+	    0x7fffffffull : ctx->rec_total / groups);
+    a.sq_cap = (uint32_t) (ctx->sq_total / groups > 0x7fffffffull?
+	    0x7fffffffull : ctx->sq_total / groups);
+    a.rec_count = ctx->d_rec_count;
+    a.sq_count = ctx->d_sq_count;
+    a.stats = ctx->d_stats;
+
+    sora_resolve_args &r = ctx->res;
+    memset(&r, 0, sizeof r);
+    r.iq = a.iq;
+    r.n_samples = n_samples;
+    r.base_position = base_position;
+    r.encoding = encoding;
+    r.emit_all = a.emit_all;
+    r.groups = groups;
+    r.rec = ctx->d_rec;
+    r.rec_count = ctx->d_rec_count;
+    r.rec_cap = a.rec_cap;
+    r.sq = ctx->d_sq;
+    r.sq_count = ctx->d_sq_count;
+    r.sq_cap = a.sq_cap;
+    r.first_seen = ctx->d_first_seen;
+    r.acc = ctx->d_acc;
+    r.acc_count = ctx->d_acc_count;
+    r.acc_cap = (uint32_t) (ctx->acc_total / groups > 0x7fffffffull?
+	    0x7fffffffull : ctx->acc_total / groups);
+    r.acc_offset = ctx->d_acc_offset;
+    r.frames = ctx->d_frames;
+    r.frames_cap = ctx->frames_cap;
+
+    ctx->groups = groups;
+    ctx->scanned = false;
+    ctx->resolved = false;
+
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_scan_begin, ctx->stream));
+    HIP_TRY(ctx, sora_launch_scan(&a, groups, ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_scan_end, ctx->stream));
+    ctx->scan_timed = true;
+    ctx->scanned = true;
+    return SORA_OK;
+}
+
+extern "C" int
+sora_adsb_squitter_count(sora_adsb_ctx *ctx, uint64_t *n) {
+    if (ctx == nullptr || n == nullptr)
+	return SORA_ERR_INVALID;
+    if (!ctx->scanned)
+	return fail(ctx, SORA_ERR_STATE, "no scan to count squitters of");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, sora_launch_scan_counts(ctx->d_sq_count, ctx->res.sq_cap,
+	    ctx->d_sq_offset, ctx->groups, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(&ctx->h_total[0], ctx->d_sq_offset + ctx->groups,
+	    sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    *n = ctx->h_total[0];
+    return SORA_OK;
+}
+
+extern "C" int
+sora_adsb_copy_squitters(sora_adsb_ctx *ctx, void *d_dst, size_t cap_records) {
+    if (ctx == nullptr || (d_dst == nullptr && cap_records != 0))
+	return SORA_ERR_INVALID;
+    if (!ctx->scanned)
+	return fail(ctx, SORA_ERR_STATE, "no scan to export squitters of");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, sora_launch_export_squitters(&ctx->res, ctx->d_sq_offset,
+	    static_cast<uint64_t *>(d_dst), cap_records, ctx->stream));
+    return SORA_OK;
+}
+
+extern "C" int
+sora_adsb_add_known(sora_adsb_ctx *ctx, const void *d_records, size_t n_records) {
+    if (ctx == nullptr || (d_records == nullptr && n_records != 0))
+	return SORA_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, sora_launch_add_known(ctx->d_first_seen,
+	    static_cast<const uint64_t *>(d_records), n_records, ctx->stream));
+    return SORA_OK;
+}
+
+extern "C" int
+sora_adsb_resolve(sora_adsb_ctx *ctx) {
+    if (ctx == nullptr)
+	return SORA_ERR_INVALID;
+    if (!ctx->scanned)
+	return fail(ctx, SORA_ERR_STATE, "resolve without a scan");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, sora_launch_first_seen(&ctx->res, ctx->stream));
+    HIP_TRY(ctx, sora_launch_filter(&ctx->res, ctx->stream));
+    HIP_TRY(ctx, sora_launch_scan_counts(ctx->d_acc_count, ctx->res.acc_cap,
+	    ctx->d_acc_offset, ctx->groups, ctx->stream));
+    HIP_TRY(ctx, sora_launch_finalize(&ctx->res, ctx->stream));
+    ctx->resolved = true;
+    return SORA_OK;
+}
+
+extern "C" int
+sora_adsb_submit_device(sora_adsb_ctx *ctx, const void *d_iq, size_t nbytes,
+	int encoding, uint64_t base_position, uint64_t n_owned) {
+    int rc = sora_adsb_scan(ctx, d_iq, nbytes, encoding, base_position, n_owned);
+    if (rc != SORA_OK)
+	return rc;
+    return sora_adsb_resolve(ctx);
+}
+
+extern "C" int
+sora_adsb_submit_host(sora_adsb_ctx *ctx, const void *h_iq, size_t nbytes,
+	int encoding, uint64_t base_position, uint64_t n_owned) {
+    if (ctx == nullptr || (h_iq == nullptr && nbytes != 0))
+	return SORA_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t need = ((nbytes + 15) & ~(size_t) 15) + 16;
+    if (ctx->stage_bytes < need) {
+	/* the stream may still read the old staging buffer */
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	(void) hipFree(ctx->d_stage);
+	ctx->d_stage = nullptr;
+	ctx->stage_bytes = 0;
+	if (hipMalloc(reinterpret_cast<void **>(&ctx->d_stage), need) != hipSuccess)
+	    return fail(ctx, SORA_ERR_NOMEM, "staging buffer of %zu bytes", need);
+	ctx->stage_bytes = need;
+    }
+    if (nbytes > 0)
+	HIP_TRY(ctx, hipMemcpyAsync(ctx->d_stage, h_iq, nbytes,
+		hipMemcpyHostToDevice, ctx->stream));
+    return sora_adsb_submit_device(ctx, ctx->d_stage, nbytes, encoding,
+	    base_position, n_owned);
+}
+
+namespace {
+
+/* copies the per-group counters to the host and checks them; syncs */
+int
+fetch_counts(sora_adsb_ctx *ctx, bool *overflow) {
+    const uint32_t g = ctx->groups;
+
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_counts, ctx->d_rec_count,
+	    g * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_counts + g, ctx->d_sq_count,
+	    g * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (ctx->resolved) {
+	HIP_TRY(ctx, hipMemcpyAsync(ctx->h_counts + 2 * g, ctx->d_acc_count,
+		g * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(ctx, hipMemcpyAsync(&ctx->h_total[1], ctx->d_acc_offset + g,
+		sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_stats, ctx->d_stats,
+	    (size_t) g * SORA_STAT_WORDS * sizeof(uint64_t),
+	    hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+
+    *overflow = false;
+    for (uint32_t i = 0; i < g; i++) {
+	if (ctx->h_counts[i] > ctx->res.rec_cap ||
+		ctx->h_counts[g + i] > ctx->res.sq_cap ||
+		(ctx->resolved && ctx->h_counts[2 * g + i] > ctx->res.acc_cap))
+	    *overflow = true;
+    }
+    if (ctx->resolved && ctx->h_total[1] > ctx->frames_cap)
+	*overflow = true;
+    return SORA_OK;
+}
+
+int
+collect_common(sora_adsb_ctx *ctx, void *dst, size_t cap, size_t *n,
+	hipMemcpyKind kind) {
+    bool overflow = false;
+
+    if (ctx == nullptr || n == nullptr || (dst == nullptr && cap != 0))
+	return SORA_ERR_INVALID;
+    *n = 0;
+    if (!ctx->resolved)
+	return fail(ctx, SORA_ERR_STATE, "collect without a resolve");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = fetch_counts(ctx, &overflow);
+    if (rc != SORA_OK)
+	return rc;
+    if (overflow)
+	return fail(ctx, SORA_ERR_OVERFLOW,
+		"a device list overflowed; raise max_candidates / max_squitters / "
+		"max_frames (see sora_adsb_get_counts)");
+    const uint64_t total = ctx->h_total[1];
+    *n = (size_t) total;
+    const size_t take = total < cap? (size_t) total : cap;
+    if (take > 0) {
+	HIP_TRY(ctx, hipMemcpyAsync(dst, ctx->d_frames, take * sizeof(sora_adsb_frame),
+		kind, ctx->stream));
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return SORA_OK;
+}
+
+} /* namespace */
+
+extern "C" int
+sora_adsb_collect(sora_adsb_ctx *ctx, sora_adsb_frame *out, size_t cap, size_t *n) {
+    return collect_common(ctx, out, cap, n, hipMemcpyDeviceToHost);
+}
+
+extern "C" int
+sora_adsb_collect_device(sora_adsb_ctx *ctx, void *d_out, size_t cap, size_t *n) {
+    return collect_common(ctx, d_out, cap, n, hipMemcpyDeviceToDevice);
+}
+
+extern "C" int
+sora_adsb_get_counts(sora_adsb_ctx *ctx, struct sora_adsb_counts *out) {
+    bool overflow = false;
+
+    if (ctx == nullptr || out == nullptr)
+	return SORA_ERR_INVALID;
+    memset(out, 0, sizeof *out);
+    if (!ctx->scanned)
+	return fail(ctx, SORA_ERR_STATE, "no scan to report on");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = fetch_counts(ctx, &overflow);
+    if (rc != SORA_OK)
+	return rc;
+    out->positions = ctx->scan.n_scan;
+    for (uint32_t i = 0; i < ctx->groups; i++) {
+	const uint64_t *st = ctx->h_stats + (size_t) i * SORA_STAT_WORDS;
+	out->candidates += st[SORA_STAT_CANDIDATES];
+	out->squitters += st[SORA_STAT_SQUITTERS];
+	out->dirty_squitters += st[SORA_STAT_DIRTY];
+	out->replies += st[SORA_STAT_REPLIES];
+	if (ctx->resolved)
+	    out->frames += ctx->h_counts[2 * ctx->groups + i];
+    }
+    return overflow? SORA_ERR_OVERFLOW : SORA_OK;
+}
+
+extern "C" int
+sora_adsb_synchronize(sora_adsb_ctx *ctx) {
+    if (ctx == nullptr)
+	return SORA_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return SORA_OK;
+}
+
+extern "C" int
+sora_adsb_last_scan_ms(sora_adsb_ctx *ctx, float *ms) {
+    if (ctx == nullptr || ms == nullptr)
+	return SORA_ERR_INVALID;
+    if (!ctx->scan_timed)
+	return fail(ctx, SORA_ERR_STATE, "no scan has been timed");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipEventSynchronize(ctx->ev_scan_end));
+    HIP_TRY(ctx, hipEventElapsedTime(ms, ctx->ev_scan_begin, ctx->ev_scan_end));
+    return SORA_OK;
+}
+
+extern "C" int
+sora_adsb_magnitude(sora_adsb_ctx *ctx, const void *d_iq, size_t nbytes,
+	int encoding, float *d_m) {
+    if (ctx == nullptr)
+	return SORA_ERR_INVALID;
+    const int bps = bytes_per_sample(encoding);
+    if (bps == 0 || (d_iq == nullptr && nbytes != 0) || (d_m == nullptr && nbytes != 0))
+	return fail(ctx, SORA_ERR_INVALID, "bad magnitude arguments");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, sora_launch_magnitude(static_cast<const uint8_t *>(d_iq),
+	    nbytes / (size_t) bps, encoding, d_m, ctx->stream));
+    return SORA_OK;
+}
+
+/* ---- device memory helpers ---- */
+
+extern "C" int
+sora_adsb_device_alloc(int device, size_t nbytes, void **d_ptr) {
+    if (d_ptr == nullptr)
+	return SORA_ERR_INVALID;
+    *d_ptr = nullptr;
+    if (hipSetDevice(device) != hipSuccess)
+	return SORA_ERR_NO_DEVICE;
+    if (hipMalloc(d_ptr, nbytes > 0? nbytes : 1) != hipSuccess)
+	return SORA_ERR_NOMEM;
+    return SORA_OK;
+}
+
+extern "C" int
+sora_adsb_device_free(int device, void *d_ptr) {
+    if (hipSetDevice(device) != hipSuccess)
+	return SORA_ERR_NO_DEVICE;
+    return hipFree(d_ptr) == hipSuccess? SORA_OK : SORA_ERR_HIP;
+}
+
+extern "C" int
+sora_adsb_copy_to_device(int device, void *d_dst, const void *h_src, size_t nbytes) {
+    if (hipSetDevice(device) != hipSuccess)
+	return SORA_ERR_NO_DEVICE;
+    if (nbytes == 0)
+	return SORA_OK;
+    return hipMemcpy(d_dst, h_src, nbytes, hipMemcpyHostToDevice) == hipSuccess?
+	    SORA_OK : SORA_ERR_HIP;
+}
+
+extern "C" int
+sora_adsb_copy_to_host(int device, void *h_dst, const void *d_src, size_t nbytes) {
+    if (hipSetDevice(device) != hipSuccess)
+	return SORA_ERR_NO_DEVICE;
+    if (nbytes == 0)
+	return SORA_OK;
+    return hipMemcpy(h_dst, d_src, nbytes, hipMemcpyDeviceToHost) == hipSuccess?
+	    SORA_OK : SORA_ERR_HIP;
+}

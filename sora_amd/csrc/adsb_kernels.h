@@ -1,0 +1,84 @@
+/*
+ * adsb_kernels.h -- launch interface between the C-ABI context
+ * (adsb_gpu.hip) and the gfx950 kernels (adsb_kernels.hip).  Internal.
+ */
+#ifndef SORA_ADSB_KERNELS_H_
+#define SORA_ADSB_KERNELS_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/sora_adsb_gpu.h"
+
+/* per-workgroup statistics written by the scan kernel */
+#define SORA_STAT_CANDIDATES	0
+#define SORA_STAT_SQUITTERS	1
+#define SORA_STAT_DIRTY		2
+#define SORA_STAT_REPLIES	3
+#define SORA_STAT_WORDS		4
+
+struct sora_scan_args {
+    const uint8_t *iq;		/* device, 16-byte aligned */
+    uint64_t n_samples;		/* samples in the chunk */
+    uint64_t n_scan;		/* positions [0, n_scan) are scanned */
+    uint64_t n_tiles;
+    int32_t encoding;
+    int32_t emit_all;		/* also record dirty squitters */
+    uint64_t *rec;		/* [groups][rec_cap] unified records */
+    uint64_t *sq;		/* [groups][sq_cap] clean squitters */
+    uint32_t rec_cap, sq_cap;	/* per-group capacities */
+    uint32_t *rec_count;	/* [groups] records produced (may exceed cap) */
+    uint32_t *sq_count;		/* [groups] */
+    uint64_t *stats;		/* [groups][SORA_STAT_WORDS] */
+};
+
+struct sora_resolve_args {
+    const uint8_t *iq;
+    uint64_t n_samples;
+    uint64_t base_position;
+    int32_t encoding;
+    int32_t emit_all;
+    uint32_t groups;
+    const uint64_t *rec;	/* scan output */
+    const uint32_t *rec_count;
+    uint32_t rec_cap;
+    const uint64_t *sq;
+    const uint32_t *sq_count;
+    uint32_t sq_cap;
+    uint64_t *first_seen;	/* [1 << 24] smallest global position, or ~0 */
+    uint64_t *acc;		/* [groups][acc_cap] accepted records */
+    uint32_t *acc_count;	/* [groups] */
+    uint32_t acc_cap;
+    uint64_t *acc_offset;	/* [groups + 1] exclusive scan of clamped counts */
+    struct sora_adsb_frame *frames;
+    uint64_t frames_cap;
+};
+
+/* tiles (workgroup passes) a chunk of n_scan positions needs */
+uint64_t sora_scan_tiles(uint64_t n_scan, int encoding);
+/* LDS bytes / thread count of the scan kernel, for documentation and tests */
+uint32_t sora_scan_lds_bytes(int encoding);
+
+hipError_t sora_launch_scan(const struct sora_scan_args *a, uint32_t groups,
+	hipStream_t stream);
+hipError_t sora_launch_fill_u64(uint64_t *dst, uint64_t value, uint64_t n,
+	hipStream_t stream);
+/* first_seen[addr] = min(first_seen[addr], base + pos) over the squitter lists */
+hipError_t sora_launch_first_seen(const struct sora_resolve_args *a,
+	hipStream_t stream);
+/* same from flat global records (position << 24 | address) */
+hipError_t sora_launch_add_known(uint64_t *first_seen, const uint64_t *records,
+	uint64_t n, hipStream_t stream);
+/* squitter lists -> flat global records; offsets = exclusive scan */
+hipError_t sora_launch_export_squitters(const struct sora_resolve_args *a,
+	uint64_t *scan_tmp, uint64_t *dst, uint64_t dst_cap, hipStream_t stream);
+hipError_t sora_launch_filter(const struct sora_resolve_args *a,
+	hipStream_t stream);
+hipError_t sora_launch_scan_counts(const uint32_t *counts, uint32_t cap,
+	uint64_t *offsets, uint32_t n, hipStream_t stream);
+hipError_t sora_launch_finalize(const struct sora_resolve_args *a,
+	hipStream_t stream);
+hipError_t sora_launch_magnitude(const uint8_t *iq, uint64_t n_samples,
+	int encoding, float *m, hipStream_t stream);
+
+#endif /* SORA_ADSB_KERNELS_H_ */

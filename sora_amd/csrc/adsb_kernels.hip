@@ -1,0 +1,702 @@
+/*
+ * adsb_kernels.hip -- gfx950 (MI355X) kernels of the ADS-B receive chain.
+ *
+ * Replaces the per-sample loop of reference src/ads-b/plane-iq.c:141-194 and
+ * the validation head of src/ads-b/plane.c:457-484.  Design notes live in
+ * DESIGN.md; the per-lane arithmetic is in adsb_tile.h.
+ *
+ * scan kernel, one 256-thread workgroup per 16128-position tile pass:
+ *   phase 1  16-byte coalesced buffer loads of raw IQ (8 samples per lane and
+ *            load), I^2+Q^2 by v_dot4_i32_i8, two 16-bit magnitudes per dword
+ *            into LDS (lane-run layout, 36-dword stride)
+ *   phase 2  every lane walks 32 pairs (64 positions) out of LDS and shifts
+ *            six compare results per pair into MSB-first bit words: NU (the
+ *            PPM slicer bit of EVERY position), D, C, split by parity
+ *   phase 3  predicate = a few word-wide ANDs of shifted words; hits are
+ *            compacted in position order into an LDS queue (block scan)
+ *   phase 4  one lane per candidate: 112 message bits are 112 consecutive
+ *            elements of an NU array (funnel shifts), CRC-24 by byte table,
+ *            DF classification; records leave in position order through an
+ *            ordered block compaction, into this workgroup's private region:
+ *            no global atomics anywhere
+ * A workgroup walks a contiguous range of tiles, so the concatenation of the
+ * regions is sorted by position by construction.
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "adsb_kernels.h"
+#include "adsb_tile.h"
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int kThreads = SORA_TILE_THREADS;
+constexpr int kWaves = kThreads / 64;
+/* the queue (u16 tile-local positions) and the CRC table reuse the M buffer
+ * once phase 2 has consumed it */
+constexpr int kQueueMax = SORA_TILE_POS / 2;		/* p and p+1 never both hit */
+constexpr int kCrcTableDword = 4096;			/* past the queue (4032 dwords) */
+static_assert(kQueueMax * 2 <= kCrcTableDword * 4, "queue overlaps CRC table");
+static_assert(kCrcTableDword + 256 <= SORA_M_DWORDS, "CRC table outside M buffer");
+
+__device__ __forceinline__ uint32_t
+lane_id() {
+    return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0));
+}
+
+/* number of set bits of a wave mask below this lane */
+__device__ __forceinline__ uint32_t
+rank_in_mask(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t) (mask >> 32),
+	    __builtin_amdgcn_mbcnt_lo((uint32_t) mask, 0));
+}
+
+__device__ __forceinline__ uint32_t
+wave_inclusive_scan(uint32_t v, uint32_t lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+	uint32_t o = __shfl_up(v, d, 64);
+	if (lane >= (uint32_t) d)
+	    v += o;
+    }
+    return v;
+}
+
+/* ------------------------------------------------------------------ scan -- */
+
+__global__ void __launch_bounds__(kThreads)
+adsb_scan8_kernel(sora_scan_args a) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_m[SORA_M_DWORDS];
+    __shared__ uint32_t s_nue[SORA_WORDS], s_nuo[SORA_WORDS];
+    __shared__ uint32_t s_de[SORA_WORDS], s_do[SORA_WORDS];
+    __shared__ uint32_t s_part[kWaves];
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63, wave = tid >> 6;
+    const uint32_t group = blockIdx.x, groups = gridDim.x;
+    const uint32_t flip = a.encoding == SORA_ENC_UC8? 0x80808080u : 0u;
+
+    /* contiguous tile range of this workgroup */
+    const uint64_t tile_begin = a.n_tiles * group / groups;
+    const uint64_t tile_end = a.n_tiles * (group + 1) / groups;
+
+    uint64_t *rec_out = a.rec + (uint64_t) group * a.rec_cap;
+    uint64_t *sq_out = a.sq + (uint64_t) group * a.sq_cap;
+    uint32_t n_rec = 0, n_sq = 0;		/* workgroup-uniform */
+    uint64_t st_cand = 0, st_sq = 0, st_dirty = 0, st_reply = 0;
+
+    uint16_t *s_queue = reinterpret_cast<uint16_t *>(s_m);
+    uint32_t *s_crc = s_m + kCrcTableDword;
+
+    for (uint64_t tile = tile_begin; tile < tile_end; tile++) {
+	const uint64_t tile_start = tile * SORA_TILE_POS;
+
+	/* ---- phase 1: load, magnitude, LDS ---- */
+	{
+	    uint64_t left = (a.n_samples - tile_start) * 2;	/* bytes */
+	    left = (left + 3) & ~3ull;		/* see sora_adsb_scan(): an odd
+						 * sample count reads its last dword whole */
+	    uint32_t span = left < (uint64_t) SORA_TILE_SAMPLES * 2?
+		    (uint32_t) left : (uint32_t) SORA_TILE_SAMPLES * 2;
+	    auto rsrc = __builtin_amdgcn_make_buffer_rsrc(
+		    const_cast<uint8_t *>(a.iq) + tile_start * 2, 0, span,
+		    0x00020000);
+	    u32x4 v[8];
+#pragma unroll
+	    for (int r = 0; r < 8; r++)
+		v[r] = __builtin_amdgcn_raw_buffer_load_b128(rsrc,
+			(r * kThreads + tid) * 16, 0, 0);
+#pragma unroll
+	    for (int r = 0; r < 8; r++) {
+		uint32_t pair = (r * kThreads + tid) * 4;
+		u32x4 m;
+		m[0] = sora_mag2_pack8(v[r][0], flip);
+		m[1] = sora_mag2_pack8(v[r][1], flip);
+		m[2] = sora_mag2_pack8(v[r][2], flip);
+		m[3] = sora_mag2_pack8(v[r][3], flip);
+		*reinterpret_cast<u32x4 *>(&s_m[pair + 4 * (pair >> 5)]) = m;
+	    }
+	    if (tid < 4)
+		s_m[kThreads * SORA_LANE_STRIDE + tid] = 0;
+	}
+	__syncthreads();
+
+	/* ---- phase 2: compare words of this lane's 32 pairs ---- */
+	uint32_t nue, nuo, de, dod, ce, co;
+	{
+	    uint32_t P[SORA_LANE_STRIDE];
+#pragma unroll
+	    for (int i = 0; i < 8; i++) {
+		u32x4 t = *reinterpret_cast<const u32x4 *>(
+			&s_m[tid * SORA_LANE_STRIDE + 4 * i]);
+		P[4 * i] = t[0]; P[4 * i + 1] = t[1];
+		P[4 * i + 2] = t[2]; P[4 * i + 3] = t[3];
+	    }
+	    {
+		u32x4 t = *reinterpret_cast<const u32x4 *>(
+			&s_m[(tid + 1) * SORA_LANE_STRIDE]);
+		P[32] = t[0]; P[33] = t[1]; P[34] = t[2]; P[35] = t[3];
+	    }
+	    sora_lane_compare(P, &nue, &nuo, &de, &dod, &ce, &co);
+	}
+	s_nue[tid] = nue;
+	s_nuo[tid] = nuo;
+	s_de[tid] = de;
+	s_do[tid] = dod;
+	if (tid == 0) {
+	    s_nue[kThreads] = 0;
+	    s_nuo[kThreads] = 0;
+	    s_de[kThreads] = 0;
+	    s_do[kThreads] = 0;
+	}
+	__syncthreads();	/* M is dead from here on: s_m becomes queue + CRC table */
+
+	/* ---- phase 3: predicate words, ordered queue of hits ---- */
+	uint32_t pe, po;
+	{
+	    uint32_t ve, vo;
+	    uint64_t left = a.n_scan - tile_start;
+	    int64_t limit = left < (uint64_t) SORA_TILE_POS? (int64_t) left
+		    : (int64_t) SORA_TILE_POS;
+
+	    sora_lane_predicate(nue, nuo, de, dod, ce, co,
+		    s_nue[tid + 1], s_nuo[tid + 1], s_de[tid + 1], s_do[tid + 1],
+		    &pe, &po);
+	    sora_lane_valid((int) tid, limit, &ve, &vo);
+	    pe &= ve;
+	    po &= vo;
+	}
+	s_crc[tid] = sora_crc24_table_entry(tid);
+
+	uint32_t cnt = __popc(pe) + __popc(po);
+	uint32_t incl = wave_inclusive_scan(cnt, lane);
+	if (lane == 63)
+	    s_part[wave] = incl;
+	__syncthreads();
+	uint32_t total = 0, off = incl - cnt;
+#pragma unroll
+	for (int w = 0; w < kWaves; w++) {
+	    uint32_t part = s_part[w];
+	    if ((uint32_t) w < wave)
+		off += part;
+	    total += part;
+	}
+	{
+	    /* a pair never hits on both parities (D[2j] & U[2j+1] vs D[2j+1]) */
+	    uint32_t both = pe | po;
+	    while (both != 0) {
+		uint32_t b = __clz(both);
+		uint32_t bit = 0x80000000u >> b;
+		s_queue[off++] = (uint16_t) (tid * SORA_LANE_POS + 2 * b +
+			((po & bit) != 0));
+		both &= ~bit;
+	    }
+	}
+	__syncthreads();
+
+	/* ---- phase 4: one lane per candidate ---- */
+	st_cand += total;
+	for (uint32_t base = 0; base < total; base += kThreads) {
+	    const uint32_t i = base + tid;
+	    const bool active = i < total;
+	    uint64_t record = 0;
+	    bool want_rec = false, want_sq = false;
+
+	    if (active) {
+		uint32_t q = s_queue[i];
+		const uint32_t *words = (q & 1)? s_nuo : s_nue;
+		uint32_t bits[4];
+		sora_candidate c;
+
+		sora_extract_bits(words, (q >> 1) + 8, bits);
+		sora_classify(bits, s_crc, &c);
+		uint64_t kind = !c.squitter? SORA_REC_KIND_REPLY :
+			c.syndrome == 0? SORA_REC_KIND_SQUITTER : SORA_REC_KIND_DIRTY;
+		record = sora_rec_make(kind, tile_start + q, c.address);
+		want_sq = kind == SORA_REC_KIND_SQUITTER;
+		want_rec = kind != SORA_REC_KIND_DIRTY || a.emit_all;
+		if (kind == SORA_REC_KIND_DIRTY)
+		    record = sora_rec_make(kind, tile_start + q, c.syndrome);
+		st_sq += want_sq;
+		st_dirty += kind == SORA_REC_KIND_DIRTY;
+		st_reply += kind == SORA_REC_KIND_REPLY;
+	    }
+
+	    /* ordered block compaction: wave masks, then wave offsets via LDS */
+	    unsigned long long m_rec = __ballot(want_rec);
+	    unsigned long long m_sq = __ballot(want_sq);
+	    if (lane == 0)
+		s_part[wave] = (uint32_t) __popcll(m_rec) |
+			((uint32_t) __popcll(m_sq) << 16);
+	    __syncthreads();
+	    uint32_t pre_rec = 0, pre_sq = 0, tot_rec = 0, tot_sq = 0;
+#pragma unroll
+	    for (int w = 0; w < kWaves; w++) {
+		uint32_t part = s_part[w];
+		if ((uint32_t) w < wave) {
+		    pre_rec += part & 0xffffu;
+		    pre_sq += part >> 16;
+		}
+		tot_rec += part & 0xffffu;
+		tot_sq += part >> 16;
+	    }
+	    if (want_rec) {
+		uint32_t idx = n_rec + pre_rec + rank_in_mask(m_rec);
+		if (idx < a.rec_cap)
+		    rec_out[idx] = record;
+	    }
+	    if (want_sq) {
+		uint32_t idx = n_sq + pre_sq + rank_in_mask(m_sq);
+		if (idx < a.sq_cap)
+		    sq_out[idx] = record;
+	    }
+	    n_rec += tot_rec;
+	    n_sq += tot_sq;
+	    __syncthreads();
+	}
+	/* every lane has passed a barrier after its last read of the queue,
+	 * the CRC table and the NU arrays, so the next tile may refill them */
+    }
+
+    /* per-workgroup results */
+    if (tid == 0) {
+	a.rec_count[group] = n_rec;
+	a.sq_count[group] = n_sq;
+    }
+    /* statistics: cand is workgroup-uniform, the others per lane */
+    {
+	uint64_t v1 = st_sq, v2 = st_dirty, v3 = st_reply;
+#pragma unroll
+	for (int d = 32; d >= 1; d >>= 1) {
+	    v1 += __shfl_xor(v1, d, 64);
+	    v2 += __shfl_xor(v2, d, 64);
+	    v3 += __shfl_xor(v3, d, 64);
+	}
+	__shared__ uint64_t s_stat[kWaves][3];
+	if (lane == 0) {
+	    s_stat[wave][0] = v1;
+	    s_stat[wave][1] = v2;
+	    s_stat[wave][2] = v3;
+	}
+	__syncthreads();
+	if (tid == 0) {
+	    uint64_t t1 = 0, t2 = 0, t3 = 0;
+	    for (int w = 0; w < kWaves; w++) {
+		t1 += s_stat[w][0];
+		t2 += s_stat[w][1];
+		t3 += s_stat[w][2];
+	    }
+	    uint64_t *st = a.stats + (uint64_t) group * SORA_STAT_WORDS;
+	    st[SORA_STAT_CANDIDATES] = st_cand;
+	    st[SORA_STAT_SQUITTERS] = t1;
+	    st[SORA_STAT_DIRTY] = t2;
+	    st[SORA_STAT_REPLIES] = t3;
+	}
+    }
+}
+
+/* ------------------------------------------------------- small kernels -- */
+
+__global__ void
+fill_u64_kernel(uint64_t *dst, uint64_t value, uint64_t n) {
+    uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t) gridDim.x * blockDim.x;
+
+    for (; i < n; i += stride)
+	dst[i] = value;
+}
+
+/* one block per workgroup region of the scan */
+__global__ void
+first_seen_kernel(sora_resolve_args a) {
+    const uint32_t group = blockIdx.x;
+    uint32_t n = a.sq_count[group];
+    const uint64_t *sq = a.sq + (uint64_t) group * a.sq_cap;
+
+    if (n > a.sq_cap)
+	n = a.sq_cap;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+	uint64_t r = sq[i];
+	atomicMin(reinterpret_cast<unsigned long long *>(
+		&a.first_seen[sora_rec_addr(r)]),
+		(unsigned long long) (a.base_position + sora_rec_pos(r)));
+    }
+}
+
+__global__ void
+add_known_kernel(uint64_t *first_seen, const uint64_t *records, uint64_t n) {
+    uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t) gridDim.x * blockDim.x;
+
+    for (; i < n; i += stride) {
+	uint64_t r = records[i];
+	atomicMin(reinterpret_cast<unsigned long long *>(
+		&first_seen[(uint32_t) r & 0xffffffu]),
+		(unsigned long long) (r >> 24));
+    }
+}
+
+/* offsets[i] = sum_{j<i} min(counts[j], cap); offsets[n] = total.  One block. */
+__global__ void __launch_bounds__(1024)
+scan_counts_kernel(const uint32_t *counts, uint32_t cap, uint64_t *offsets,
+	uint32_t n) {
+    __shared__ uint64_t s_wave[16];
+    __shared__ uint64_t s_carry;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    if (tid == 0)
+	s_carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += 1024) {
+	uint32_t i = base + tid;
+	uint64_t c = 0;
+	if (i < n) {
+	    c = counts[i];
+	    if (c > cap)
+		c = cap;
+	}
+	uint64_t incl = c;
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) {
+	    uint64_t o = __shfl_up(incl, d, 64);
+	    if (lane >= (uint32_t) d)
+		incl += o;
+	}
+	if (lane == 63)
+	    s_wave[wave] = incl;
+	__syncthreads();
+	uint64_t pre = s_carry;
+	for (uint32_t w = 0; w < wave; w++)
+	    pre += s_wave[w];
+	if (i < n)
+	    offsets[i] = pre + incl - c;
+	__syncthreads();
+	if (tid == 1023)
+	    s_carry = pre + incl;
+	__syncthreads();
+    }
+    if (tid == 0)
+	offsets[n] = s_carry;
+}
+
+/* squitter regions -> flat records (global position << 24 | address) */
+__global__ void
+export_squitters_kernel(sora_resolve_args a, const uint64_t *offsets,
+	uint64_t *dst, uint64_t dst_cap) {
+    const uint32_t group = blockIdx.x;
+    uint32_t n = a.sq_count[group];
+    const uint64_t *sq = a.sq + (uint64_t) group * a.sq_cap;
+    const uint64_t off = offsets[group];
+
+    if (n > a.sq_cap)
+	n = a.sq_cap;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+	uint64_t r = sq[i];
+	if (off + i < dst_cap)
+	    dst[off + i] = ((a.base_position + sora_rec_pos(r)) << 24) |
+		    sora_rec_addr(r);
+    }
+}
+
+/*
+ * The stateful rule of plane.c:479-483 as a pure function: a reply at global
+ * position P with address A is accepted iff first_seen[A] < P.  Order
+ * preserving compaction of each region into the accepted list.
+ */
+__global__ void __launch_bounds__(kThreads)
+filter_kernel(sora_resolve_args a) {
+    __shared__ uint32_t s_part[kWaves];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t group = blockIdx.x;
+    const uint64_t *rec = a.rec + (uint64_t) group * a.rec_cap;
+    uint64_t *acc = a.acc + (uint64_t) group * a.acc_cap;
+    uint32_t n = a.rec_count[group];
+    uint32_t n_acc = 0;
+
+    if (n > a.rec_cap)
+	n = a.rec_cap;
+    for (uint32_t base = 0; base < n; base += kThreads) {
+	const uint32_t i = base + tid;
+	bool keep = false;
+	uint64_t r = 0;
+
+	if (i < n) {
+	    r = rec[i];
+	    uint32_t kind = sora_rec_kind(r);
+	    if (kind == SORA_REC_KIND_SQUITTER) {
+		keep = true;
+		r |= SORA_REC_ACCEPTED << 60;
+	    } else if (kind == SORA_REC_KIND_REPLY) {
+		bool known = a.first_seen[sora_rec_addr(r)] <
+			a.base_position + sora_rec_pos(r);
+		if (known)
+		    r |= SORA_REC_ACCEPTED << 60;
+		keep = known || a.emit_all;
+	    } else {
+		keep = a.emit_all != 0;
+	    }
+	}
+	/* survivors are rare: most rounds keep nothing (workgroup-uniform test) */
+	if (__syncthreads_or(keep) == 0)
+	    continue;
+	unsigned long long m = __ballot(keep);
+	if (lane == 0)
+	    s_part[wave] = (uint32_t) __popcll(m);
+	__syncthreads();
+	uint32_t pre = 0, tot = 0;
+#pragma unroll
+	for (int w = 0; w < kWaves; w++) {
+	    uint32_t part = s_part[w];
+	    if ((uint32_t) w < wave)
+		pre += part;
+	    tot += part;
+	}
+	if (keep) {
+	    uint32_t idx = n_acc + pre + rank_in_mask(m);
+	    if (idx < a.acc_cap)
+		acc[idx] = r;
+	}
+	n_acc += tot;
+	__syncthreads();
+    }
+    if (tid == 0)
+	a.acc_count[group] = n_acc;
+}
+
+/* x^n mod G for n = 0..111, G = 0x1FFF409: the CRC contribution of one bit */
+struct crc_powers {
+    uint32_t r[112];
+    constexpr crc_powers() : r{} {
+	uint32_t v = 1;
+	for (int n = 0; n < 112; n++) {
+	    r[n] = v;
+	    v <<= 1;
+	    if (v & 0x1000000u)
+		v ^= 0x1fff409u;
+	}
+    }
+};
+__constant__ crc_powers c_crc_pow = crc_powers();
+
+__device__ __forceinline__ float
+magnitude_f32(const uint8_t *iq, uint64_t i, int encoding) {
+    /* row a1; float result is exact for the 8-bit encodings */
+    if (encoding == SORA_ENC_SC16) {
+	const int16_t *s = reinterpret_cast<const int16_t *>(iq) + 2 * i;
+	float re = (float) s[0] * (1.0f / 32768.0f);
+	float im = (float) s[1] * (1.0f / 32768.0f);
+	return __fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im));
+    }
+    int vi, vq;
+    if (encoding == SORA_ENC_UC8) {
+	vi = (int) iq[2 * i] - 128;
+	vq = (int) iq[2 * i + 1] - 128;
+    } else {
+	vi = (int8_t) iq[2 * i];
+	vq = (int8_t) iq[2 * i + 1];
+    }
+    return (float) (vi * vi + vq * vq) * (1.0f / 16384.0f);
+}
+
+/*
+ * Re-slices every accepted position from the raw samples in HBM, one wave
+ * per frame: the independent second implementation of the slicer
+ * (plane-iq.c:58-86) and of the CRC (plane.c:373-385), and the only place
+ * amplitudes are computed (only accepted frames need them).
+ */
+__global__ void __launch_bounds__(kThreads)
+finalize_kernel(sora_resolve_args a) {
+    __shared__ float s_amp[kWaves][56];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t group = blockIdx.x;
+    const uint64_t *acc = a.acc + (uint64_t) group * a.acc_cap;
+    uint32_t n = a.acc_count[group];
+    const uint64_t out0 = a.acc_offset[group];
+
+    if (n > a.acc_cap)
+	n = a.acc_cap;
+    for (uint32_t i = wave; i < n; i += kWaves) {
+	const uint64_t r = acc[i];
+	const uint64_t p = sora_rec_pos(r);
+	const uint64_t s = p + 16;
+
+	/* bit k = m[p+17+2k] <= m[p+16+2k], k = lane and k = 64 + lane */
+	float a0 = magnitude_f32(a.iq, s + 2 * lane, a.encoding);
+	float a1 = magnitude_f32(a.iq, s + 2 * lane + 1, a.encoding);
+	float b0 = 0, b1 = 1;
+	if (lane < 48) {
+	    b0 = magnitude_f32(a.iq, s + 128 + 2 * lane, a.encoding);
+	    b1 = magnitude_f32(a.iq, s + 128 + 2 * lane + 1, a.encoding);
+	}
+	unsigned long long lo = __ballot(a1 <= a0);
+	unsigned long long hi = __ballot(lane < 48 && b1 <= b0);
+	uint32_t bits[4];
+	bits[0] = __brev((uint32_t) lo);
+	bits[1] = __brev((uint32_t) (lo >> 32));
+	bits[2] = __brev((uint32_t) hi);
+	bits[3] = __brev((uint32_t) (hi >> 32)) & 0xffff0000u;
+
+	/* plane.c:461-475 */
+	const uint32_t df = bits[0] >> 27;
+	const bool is_long = df >= 16 && df <= 24;
+	const int covered = is_long? 88 : 32;
+	uint32_t x = 0;
+	if ((int) lane < covered && ((lo >> lane) & 1))
+	    x = c_crc_pow.r[covered + 23 - lane];
+	if ((int) lane + 64 < covered && ((hi >> lane) & 1))
+	    x ^= c_crc_pow.r[covered + 23 - 64 - lane];
+#pragma unroll
+	for (int d = 32; d >= 1; d >>= 1)
+	    x ^= __shfl_xor(x, d, 64);
+	const uint32_t ap = is_long? (((bits[2] & 0xffu) << 16) | (bits[3] >> 16))
+		: (bits[1] >> 8);
+	const uint32_t syndrome = x ^ ap;
+	const bool squitter = df == 11 || df == 17 || df == 18;
+
+	/* plane-iq.c:62-73: float (s0+s1)/2 accumulated in double, in order */
+	if (lane < 56)
+	    s_amp[wave][lane] = __fmul_rn(__fadd_rn(a0, a1), 0.5f);
+	uint32_t sum56 = 0;
+	if (a.encoding != SORA_ENC_SC16) {
+	    /* integers: M = m * 2^14 exactly */
+	    sum56 = lane < 56? (uint32_t) (__fadd_rn(a0, a1) * 16384.0f) : 0;
+#pragma unroll
+	    for (int d = 32; d >= 1; d >>= 1)
+		sum56 += __shfl_xor(sum56, d, 64);
+	}
+	__builtin_amdgcn_wave_barrier();
+	if (lane == 0 && out0 + i < a.frames_cap) {
+	    double a56 = 0;
+	    for (int k = 0; k < 56; k++)
+		a56 += (double) s_amp[wave][k];
+	    sora_adsb_frame f;
+	    f.position = a.base_position + p;
+	    f.bits[0] = bits[0]; f.bits[1] = bits[1];
+	    f.bits[2] = bits[2]; f.bits[3] = bits[3];
+	    f.amplitude_56 = a56;
+	    f.syndrome = syndrome;
+	    f.address = squitter? (bits[0] & 0xffffffu) : syndrome;
+	    f.sum56 = sum56;
+	    f.df = (uint8_t) df;
+	    f.corrected_bit = -1;
+	    f.flags = (uint8_t) ((is_long? SORA_FRAME_LONG : 0) |
+		    (squitter? SORA_FRAME_SQUITTER : 0) |
+		    ((sora_rec_kind(r) & SORA_REC_ACCEPTED)? SORA_FRAME_ACCEPTED : 0));
+	    f.reserved = 0;
+	    a.frames[out0 + i] = f;
+	}
+	__builtin_amdgcn_wave_barrier();
+    }
+}
+
+__global__ void
+magnitude_kernel(const uint8_t *iq, uint64_t n, int encoding, float *m) {
+    uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t) gridDim.x * blockDim.x;
+
+    for (; i < n; i += stride)
+	m[i] = magnitude_f32(iq, i, encoding);
+}
+
+uint32_t
+grid_for(uint64_t n, uint32_t block) {
+    uint64_t g = (n + block - 1) / block;
+    return g < 1? 1 : g > 8192? 8192 : (uint32_t) g;
+}
+
+} /* namespace */
+
+/* ---------------------------------------------------------- launchers -- */
+
+uint64_t
+sora_scan_tiles(uint64_t n_scan, int encoding) {
+    (void) encoding;
+    return (n_scan + SORA_TILE_POS - 1) / SORA_TILE_POS;
+}
+
+uint32_t
+sora_scan_lds_bytes(int encoding) {
+    (void) encoding;
+    return (uint32_t) ((SORA_M_DWORDS + 4 * SORA_WORDS + kWaves) * 4 +
+	    kWaves * 3 * 8);
+}
+
+hipError_t
+sora_launch_scan(const sora_scan_args *a, uint32_t groups, hipStream_t stream) {
+    if (a->encoding != SORA_ENC_UC8 && a->encoding != SORA_ENC_SC8)
+	return hipErrorInvalidValue;
+    hipLaunchKernelGGL(adsb_scan8_kernel, dim3(groups), dim3(kThreads), 0,
+	    stream, *a);
+    return hipGetLastError();
+}
+
+hipError_t
+sora_launch_fill_u64(uint64_t *dst, uint64_t value, uint64_t n,
+	hipStream_t stream) {
+    hipLaunchKernelGGL(fill_u64_kernel, dim3(grid_for(n, 256)), dim3(256), 0,
+	    stream, dst, value, n);
+    return hipGetLastError();
+}
+
+hipError_t
+sora_launch_first_seen(const sora_resolve_args *a, hipStream_t stream) {
+    hipLaunchKernelGGL(first_seen_kernel, dim3(a->groups), dim3(256), 0, stream,
+	    *a);
+    return hipGetLastError();
+}
+
+hipError_t
+sora_launch_add_known(uint64_t *first_seen, const uint64_t *records,
+	uint64_t n, hipStream_t stream) {
+    if (n == 0)
+	return hipSuccess;
+    hipLaunchKernelGGL(add_known_kernel, dim3(grid_for(n, 256)), dim3(256), 0,
+	    stream, first_seen, records, n);
+    return hipGetLastError();
+}
+
+hipError_t
+sora_launch_scan_counts(const uint32_t *counts, uint32_t cap,
+	uint64_t *offsets, uint32_t n, hipStream_t stream) {
+    hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream,
+	    counts, cap, offsets, n);
+    return hipGetLastError();
+}
+
+hipError_t
+sora_launch_export_squitters(const sora_resolve_args *a, uint64_t *scan_tmp,
+	uint64_t *dst, uint64_t dst_cap, hipStream_t stream) {
+    hipError_t e = sora_launch_scan_counts(a->sq_count, a->sq_cap, scan_tmp,
+	    a->groups, stream);
+    if (e != hipSuccess)
+	return e;
+    hipLaunchKernelGGL(export_squitters_kernel, dim3(a->groups), dim3(256), 0,
+	    stream, *a, scan_tmp, dst, dst_cap);
+    return hipGetLastError();
+}
+
+hipError_t
+sora_launch_filter(const sora_resolve_args *a, hipStream_t stream) {
+    hipLaunchKernelGGL(filter_kernel, dim3(a->groups), dim3(kThreads), 0,
+	    stream, *a);
+    return hipGetLastError();
+}
+
+hipError_t
+sora_launch_finalize(const sora_resolve_args *a, hipStream_t stream) {
+    hipLaunchKernelGGL(finalize_kernel, dim3(a->groups), dim3(kThreads), 0,
+	    stream, *a);
+    return hipGetLastError();
+}
+
+hipError_t
+sora_launch_magnitude(const uint8_t *iq, uint64_t n_samples, int encoding,
+	float *m, hipStream_t stream) {
+    if (n_samples == 0)
+	return hipSuccess;
+    hipLaunchKernelGGL(magnitude_kernel, dim3(grid_for(n_samples, 256)),
+	    dim3(256), 0, stream, iq, n_samples, encoding, m);
+    return hipGetLastError();
+}
