@@ -1,0 +1,177 @@
+"""Context wrapper over the C ABI (include/sora_adsb_gpu.h)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import (BYTES_PER_SAMPLE, Config, Counts, EMIT_ACCEPTED, FRAME_DTYPE, check,
+                   lib)
+
+
+def _ptr(buf):
+    """Device address of a DeviceBuffer, a torch CUDA tensor or a raw int."""
+    if isinstance(buf, DeviceBuffer):
+        return buf.ptr
+    if isinstance(buf, int):
+        return buf
+    if hasattr(buf, "data_ptr"):        # torch tensor
+        if not buf.is_cuda:
+            raise ValueError("expected a device tensor")
+        if not buf.is_contiguous():
+            raise ValueError("expected a contiguous tensor")
+        return buf.data_ptr()
+    raise TypeError(f"cannot take a device pointer from {type(buf)!r}")
+
+
+class DeviceBuffer:
+    """hipMalloc'd bytes, for callers that do not want torch."""
+
+    def __init__(self, nbytes, device=0):
+        self.device = device
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        check(lib().sora_adsb_device_alloc(device, self.nbytes, C.byref(p)))
+        self.ptr = p.value
+
+    @classmethod
+    def from_host(cls, data, device=0):
+        arr = np.ascontiguousarray(np.frombuffer(data, dtype=np.uint8))
+        buf = cls(arr.size, device)
+        check(lib().sora_adsb_copy_to_device(device, buf.ptr, arr.ctypes.data, arr.size))
+        return buf
+
+    def to_host(self, nbytes=None):
+        n = self.nbytes if nbytes is None else int(nbytes)
+        out = np.empty(n, dtype=np.uint8)
+        check(lib().sora_adsb_copy_to_host(self.device, out.ctypes.data, self.ptr, n))
+        return out
+
+    def free(self):
+        if self.ptr:
+            lib().sora_adsb_device_free(self.device, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class AdsbContext:
+    """One device, one stream of samples (struct sora_adsb_ctx)."""
+
+    def __init__(self, max_chunk_samples, device=0, emit_mode=EMIT_ACCEPTED,
+                 max_candidates=0, max_squitters=0, max_frames=0, stream=None):
+        self.device = device
+        cfg = Config(int(max_chunk_samples), int(max_candidates), int(max_squitters),
+                     int(max_frames), int(emit_mode), 0, stream)
+        h = C.c_void_p()
+        rc = lib().sora_adsb_create(C.byref(h), device, C.byref(cfg))
+        self._h = h.value
+        if rc != _lib.OK:
+            detail = lib().sora_adsb_last_error(self._h).decode() if self._h else ""
+            if self._h:
+                lib().sora_adsb_destroy(self._h)
+                self._h = None
+            raise _lib.SoraError(rc, detail)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().sora_adsb_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def reset(self):
+        check(lib().sora_adsb_reset(self._h), self._h)
+
+    # -- stage 1 / exchange / stage 2 ------------------------------------
+    def scan(self, d_iq, nbytes, encoding, base_position=0, n_owned=None):
+        n_samples = nbytes // BYTES_PER_SAMPLE[encoding]
+        if n_owned is None:
+            n_owned = n_samples
+        check(lib().sora_adsb_scan(self._h, _ptr(d_iq), nbytes, encoding, base_position,
+                                   n_owned), self._h)
+
+    def squitter_count(self):
+        n = C.c_uint64()
+        check(lib().sora_adsb_squitter_count(self._h, C.byref(n)), self._h)
+        return n.value
+
+    def copy_squitters(self, d_dst, cap_records):
+        check(lib().sora_adsb_copy_squitters(self._h, _ptr(d_dst), cap_records), self._h)
+
+    def add_known(self, d_records, n_records):
+        check(lib().sora_adsb_add_known(self._h, _ptr(d_records), n_records), self._h)
+
+    def resolve(self):
+        check(lib().sora_adsb_resolve(self._h), self._h)
+
+    def submit_device(self, d_iq, nbytes, encoding, base_position=0, n_owned=None):
+        n_samples = nbytes // BYTES_PER_SAMPLE[encoding]
+        if n_owned is None:
+            n_owned = n_samples
+        check(lib().sora_adsb_submit_device(self._h, _ptr(d_iq), nbytes, encoding,
+                                            base_position, n_owned), self._h)
+
+    def submit_host(self, data, encoding, base_position=0, n_owned=None):
+        arr = np.ascontiguousarray(np.frombuffer(data, dtype=np.uint8))
+        n_samples = arr.size // BYTES_PER_SAMPLE[encoding]
+        if n_owned is None:
+            n_owned = n_samples
+        check(lib().sora_adsb_submit_host(self._h, arr.ctypes.data, arr.size, encoding,
+                                          base_position, n_owned), self._h)
+
+    # -- results ----------------------------------------------------------
+    def collect(self, cap=None):
+        """Frames of the last resolve as a numpy structured array (FRAME_DTYPE)."""
+        n = C.c_size_t()
+        if cap is None:
+            # ask for the count first, then fetch exactly that many
+            check(lib().sora_adsb_collect(self._h, None, 0, C.byref(n)), self._h)
+            cap = n.value
+        out = np.zeros(cap, dtype=FRAME_DTYPE)
+        check(lib().sora_adsb_collect(self._h, out.ctypes.data if cap else None, cap,
+                                      C.byref(n)), self._h)
+        return out[:min(cap, n.value)]
+
+    def collect_into(self, out):
+        """Frames into a preallocated (ideally pinned) numpy array; returns count."""
+        n = C.c_size_t()
+        check(lib().sora_adsb_collect(self._h, out.ctypes.data, out.size, C.byref(n)),
+              self._h)
+        return n.value
+
+    def collect_device(self, d_out, cap):
+        n = C.c_size_t()
+        check(lib().sora_adsb_collect_device(self._h, _ptr(d_out), cap, C.byref(n)),
+              self._h)
+        return n.value
+
+    def counts(self):
+        c = Counts()
+        rc = lib().sora_adsb_get_counts(self._h, C.byref(c))
+        if rc not in (_lib.OK, _lib.ERR_OVERFLOW):
+            check(rc, self._h)
+        d = {k: getattr(c, k) for k, _ in Counts._fields_}
+        d["overflow"] = rc == _lib.ERR_OVERFLOW
+        return d
+
+    def synchronize(self):
+        check(lib().sora_adsb_synchronize(self._h), self._h)
+
+    def last_scan_ms(self):
+        ms = C.c_float()
+        check(lib().sora_adsb_last_scan_ms(self._h, C.byref(ms)), self._h)
+        return ms.value
+
+    def magnitude(self, d_iq, nbytes, encoding, d_m):
+        check(lib().sora_adsb_magnitude(self._h, _ptr(d_iq), nbytes, encoding, _ptr(d_m)),
+              self._h)

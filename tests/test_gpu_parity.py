@@ -1,0 +1,258 @@
+"""GPU tier (-m gpu): the gfx950 path, called through the C ABI, against the
+oracle on the same inputs, against the golden vectors of the compiled
+reference, and -- at sizes the oracle cannot walk -- through size-independent
+properties.  Bar: bit-exact (positions, 112 bits, amplitude_56 as a double,
+DF, syndrome, address, accepted flag)."""
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+import sora_amd
+from conftest import GOLDEN_NAMES, assert_same_frames, frames_as_dicts, load_golden
+from sora_amd import (EMIT_ACCEPTED, EMIT_CANDIDATES, ENC_SC8, ENC_SC16, ENC_UC8,
+                      AdsbContext, DeviceBuffer, synth)
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu_frames(raw, encoding=ENC_UC8, emit=EMIT_CANDIDATES, host=False, **kw):
+    raw = bytes(raw)
+    n = len(raw) // sora_amd._lib.BYTES_PER_SAMPLE[encoding]
+    with AdsbContext(max(n, 1), emit_mode=emit, max_candidates=n // 2 + 1024,
+                     max_squitters=n // 2 + 1024, **kw) as ctx:
+        if host:
+            ctx.submit_host(raw, encoding)
+        else:
+            buf = DeviceBuffer.from_host(raw + bytes(16))
+            ctx.submit_device(buf, len(raw), encoding)
+        frames = ctx.collect()
+        counts = ctx.counts()
+    return frames_as_dicts(frames), counts
+
+
+@pytest.mark.parametrize("name", GOLDEN_NAMES)
+def test_golden_candidates(name):
+    raw, cands, _ = load_golden(name)
+    got, counts = gpu_frames(raw)
+    assert_same_frames(got, cands, fields=("position", "bits", "amplitude_56",
+                                            "amplitude", "accepted"))
+    assert counts["candidates"] == len(cands)
+
+
+@pytest.mark.parametrize("name", GOLDEN_NAMES)
+def test_golden_accepted(name):
+    raw, cands, _ = load_golden(name)
+    got, _ = gpu_frames(raw, emit=EMIT_ACCEPTED, host=True)
+    assert_same_frames(got, [c for c in cands if c["accepted"]],
+                       fields=("position", "bits", "amplitude_56", "amplitude",
+                               "accepted"))
+
+
+@pytest.mark.parametrize("enc", [ENC_UC8, ENC_SC8])
+def test_uniform_noise_all_fields(enc):
+    rng = np.random.default_rng(100 + enc)
+    raw = rng.integers(0, 256, size=2 * 300007, dtype=np.uint8).tobytes()
+    got, counts = gpu_frames(raw, enc)
+    want = ob.scan(raw, enc)
+    assert_same_frames(got, want)
+    assert counts["candidates"] == len(want)
+    assert counts["replies"] + counts["squitters"] + counts["dirty_squitters"] == len(want)
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_mixed_traffic_all_fields(seed):
+    p = synth.default_params(2, n_samples=1500000, mean_gap=800, reply_permille=200,
+                             unknown_permille=300, n_icao=7, seed=seed)
+    raw = synth.fill_host(p.n_samples, p.encoding, p.seed, synth.make_frames(p)).tobytes()
+    want = ob.scan(raw)
+    got, _ = gpu_frames(raw)
+    assert_same_frames(got, want)
+    acc, _ = gpu_frames(raw, emit=EMIT_ACCEPTED)
+    assert_same_frames(acc, [c for c in want if c["accepted"]])
+    assert sum(1 for c in want if c["accepted"] and c["df"] not in (11, 17, 18)) > 10
+
+
+@pytest.mark.parametrize("n", [0, 1, 17, 239, 240, 241, 255, 16128 + 239, 16128 + 240,
+                               16367, 16368, 16384, 2 * 16128 + 238])
+def test_edge_lengths(n):
+    rng = np.random.default_rng(n)
+    raw = rng.integers(0, 256, size=2 * n, dtype=np.uint8).tobytes()
+    got, _ = gpu_frames(raw)
+    assert_same_frames(got, ob.scan(raw))
+
+
+def test_ties_and_constant_input():
+    """Constant input: every compare is a tie, the strict predicate never fires."""
+    got, counts = gpu_frames(bytes([128]) * 100000)
+    assert got == [] and counts["candidates"] == 0
+    got, _ = gpu_frames(bytes([0, 255] * 50000))
+    assert got == []
+
+
+def test_frames_on_tile_edges():
+    klm = synth.hex_to_bits("8D4840D6202CC371C32CE0576098")
+    T = 16128
+    edges = [T - 241, T + 10, 2 * T - 17, 3 * T - 1, 4 * T, 5 * T + 1, 6 * T - 64,
+             6 * T + 256, 7 * T - 239]
+    table = synth.frame_table([(p, klm, 70, 0, 112) for p in edges])
+    raw = synth.fill_host(7 * T + 500, ENC_UC8, 99, table).tobytes()
+    want = ob.scan(raw)
+    got, _ = gpu_frames(raw)
+    assert_same_frames(got, want)
+    assert set(edges) <= {c["position"] for c in got if c["accepted"]}
+
+
+def test_magnitude_bit_exact():
+    """Row a1; north_star allows 1 ulp, the kernels are exact."""
+    import torch
+    rng = np.random.default_rng(3)
+    for enc, nbytes in ((ENC_UC8, 2 * 70001), (ENC_SC8, 2 * 70001), (ENC_SC16, 4 * 70001)):
+        raw = rng.integers(0, 256, size=nbytes, dtype=np.uint8)
+        d = torch.from_numpy(raw).cuda()
+        n = nbytes // sora_amd._lib.BYTES_PER_SAMPLE[enc]
+        m = torch.empty(n, dtype=torch.float32, device="cuda")
+        with AdsbContext(n) as ctx:
+            ctx.magnitude(d, nbytes, enc, m)
+            ctx.synchronize()
+        want = ob.magnitude(raw.tobytes(), enc)
+        assert np.array_equal(m.cpu().numpy().view(np.uint32), want.view(np.uint32))
+
+
+def test_streaming_chunks_equal_whole():
+    """Known addresses persist across submits (planes never expire, plane.c:90-105);
+    a chunk carries a 239-sample halo."""
+    p = synth.default_params(2, n_samples=900000, mean_gap=900, reply_permille=250,
+                             unknown_permille=200, n_icao=5, seed=77)
+    raw = synth.fill_host(p.n_samples, p.encoding, p.seed, synth.make_frames(p)).tobytes()
+    want = [c for c in ob.scan(raw) if c["accepted"]]
+    cuts = [0, 250001, 250002, 600000, 900000]
+    got = []
+    with AdsbContext(400000 + 239) as ctx:
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            last = b == cuts[-1]
+            end = b if last else b + 239
+            ctx.submit_host(raw[2 * a:2 * end], ENC_UC8, base_position=a,
+                            n_owned=b - a)
+            got += frames_as_dicts(ctx.collect())
+    assert_same_frames(got, want)
+
+
+def test_shard_exchange_equals_whole():
+    """Two time shards scanned independently; squitter records exchanged."""
+    import torch
+    p = synth.default_params(2, n_samples=800000, mean_gap=1000, reply_permille=300,
+                             unknown_permille=200, n_icao=4, seed=5)
+    raw = synth.fill_host(p.n_samples, p.encoding, p.seed, synth.make_frames(p)).tobytes()
+    want = [c for c in ob.scan(raw) if c["accepted"]]
+    half = 400000
+    shards = [(0, half, half + 239), (half, p.n_samples - half, p.n_samples - half)]
+    ctxs = [AdsbContext(half + 239) for _ in shards]
+    bufs, recs = [], []
+    for ctx, (a, owned, n) in zip(ctxs, shards):
+        buf = DeviceBuffer.from_host(raw[2 * a:2 * (a + n)] + bytes(16))
+        bufs.append(buf)
+        ctx.scan(buf, 2 * n, ENC_UC8, base_position=a, n_owned=owned)
+        k = ctx.squitter_count()
+        t = torch.zeros(max(k, 1), dtype=torch.int64, device="cuda")
+        ctx.copy_squitters(t, k)
+        ctx.synchronize()
+        recs.append((t, k))
+    got = []
+    for i, ctx in enumerate(ctxs):
+        for j, (t, k) in enumerate(recs):
+            if j != i:
+                ctx.add_known(t, k)
+        ctx.resolve()
+        got += frames_as_dicts(ctx.collect())
+        ctx.close()
+    assert_same_frames(got, want)
+
+
+def test_overflow_is_reported():
+    rng = np.random.default_rng(1)
+    raw = rng.integers(0, 256, size=2 * 200000, dtype=np.uint8).tobytes()
+    with AdsbContext(200000, max_candidates=100) as ctx:
+        ctx.submit_host(raw, ENC_UC8)
+        with pytest.raises(sora_amd.SoraError) as e:
+            ctx.collect()
+        assert e.value.code == sora_amd._lib.ERR_OVERFLOW
+        assert ctx.counts()["overflow"]
+
+
+def test_bad_arguments():
+    with AdsbContext(1000) as ctx:
+        buf = DeviceBuffer(4096)
+        with pytest.raises(sora_amd.SoraError) as e:
+            ctx.scan(buf.ptr + 2, 100, ENC_UC8)
+        assert e.value.code == sora_amd._lib.ERR_ALIGN
+        with pytest.raises(sora_amd.SoraError) as e:
+            ctx.scan(buf, 4096, ENC_UC8)            # 2048 samples > max_chunk 1000
+        assert e.value.code == sora_amd._lib.ERR_INVALID
+        with pytest.raises(sora_amd.SoraError) as e:
+            ctx.collect()
+        assert e.value.code == sora_amd._lib.ERR_STATE
+
+
+def test_device_fill_equals_host_fill():
+    import torch
+    p = synth.default_params(2, n_samples=3000001, mean_gap=600)
+    fr = synth.make_frames(p)
+    for enc in (ENC_UC8, ENC_SC8, ENC_SC16):
+        nb = p.n_samples * sora_amd._lib.BYTES_PER_SAMPLE[enc]
+        d = torch.zeros(nb, dtype=torch.uint8, device="cuda")
+        fr2 = fr.copy()
+        if enc == ENC_SC16:
+            fr2["amp_i"] *= 100
+            fr2["amp_q"] *= 100
+        synth.fill_device(d.data_ptr(), p.n_samples, enc, p.seed, fr2)
+        want = synth.fill_host(p.n_samples, enc, p.seed, fr2)
+        assert np.array_equal(d.cpu().numpy(), want)
+
+
+def test_config1_size_properties():
+    """BASELINE config 1 size (120 M samples, 240 MB): properties that need no
+    oracle walk -- sorted output, every strong injected DF17 recovered
+    bit-exactly, idempotence, and the chunked result equal to the whole."""
+    import torch
+    p = synth.default_params(1)
+    fr = synth.make_frames(p)
+    d = torch.empty(2 * p.n_samples, dtype=torch.uint8, device="cuda")
+    synth.fill_device(d.data_ptr(), p.n_samples, p.encoding, p.seed, fr)
+    with AdsbContext(p.n_samples) as ctx:
+        ctx.submit_device(d, 2 * p.n_samples, ENC_UC8)
+        a = ctx.collect()
+        ctx.reset()
+        ctx.submit_device(d, 2 * p.n_samples, ENC_UC8)
+        b = ctx.collect()
+        counts = ctx.counts()
+    assert a.tobytes() == b.tobytes()                       # idempotent
+    pos = a["position"].astype(np.int64)
+    assert np.all(np.diff(pos) > 0)                         # sorted, unique
+    assert 0.015 < counts["candidates"] / p.n_samples < 0.03
+    got = {int(f["position"]): f for f in a}
+    df17 = [f for f in fr if int(f["kind"]) == synth.KIND_DF17]
+    hit = sum(1 for f in df17 if int(f["position"]) in got and
+              np.array_equal(got[int(f["position"])]["bits"], f["bits"]))
+    assert hit >= 0.9 * len(df17)
+    # a 4 M-sample window in the middle against the oracle, exactly
+    lo, n = 60000000, 4000000
+    raw = d[2 * lo:2 * (lo + n)].cpu().numpy().tobytes()
+    ps = ob.PlaneSet()
+    for f in a[pos < lo]:                                   # addresses known so far
+        if int(f["flags"]) & sora_amd.FRAME_SQUITTER:
+            ps.parse(sora_amd.bits_to_string(f["bits"]))
+    want = [c for c in ob.scan(raw, base_position=lo, plane_set=ps) if c["accepted"]]
+    window = frames_as_dicts(a[(pos >= lo) & (pos < lo + n - 239)])
+    assert_same_frames(window, want)
+    # chunked with halos, 7 ragged chunks
+    # (a device chunk must start 16-byte aligned: shard starts are multiples of 8)
+    cuts = np.linspace(0, p.n_samples, 8).astype(np.int64) // 8 * 8
+    cuts[1:-1] += np.array([8, 56, 64, 136, 1000, 16120])
+    out = []
+    with AdsbContext(int(np.diff(cuts).max()) + 239) as ctx:
+        for s, e in zip(cuts[:-1], cuts[1:]):
+            end = int(e) if e == cuts[-1] else int(e) + 239
+            ctx.submit_device(d.data_ptr() + 2 * int(s), 2 * (end - int(s)), ENC_UC8,
+                              base_position=int(s), n_owned=int(e - s))
+            out.append(ctx.collect())
+    assert np.concatenate(out).tobytes() == a.tobytes()
