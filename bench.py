@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""bench.py -- Msamples/s of the ADS-B receive chain on N MI355X.
+
+A step is one pass of the hot path over one synthetic capture that is already
+resident in HBM: scan kernel -> (N>1: squitter-record exchange over RCCL) ->
+first-seen merge, reply filter, re-slice of the accepted frames -> frame list
+in host memory (N>1: gathered to rank 0 over RCCL first).  At N=1 the workload
+is BASELINE.json configs[1]: a 1-hour 2 MS/s uc8 capture (7.2 G samples,
+14.4 GB) with DF17/DF11 at mixed SNR.  For N>1 every rank holds one such
+1-hour shard of an N-hour capture (weak scaling), 239 halo samples behind it.
+
+    python bench.py --gpus 1 --steps 10 --warmup 2
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec peak
+BYTES_PER_SAMPLE = 2        # uc8: the algorithmic traffic, SURVEY.md section 8d
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--samples", type=float, default=7.2e9,
+                    help="samples per GPU (default: 1 hour at 2 MS/s)")
+    ap.add_argument("--cpu-samples", type=float, default=120e6,
+                    help="bounded sample for the CPU baseline leg (0 = skip)")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="run the N>1 exchange code path even with one rank (rehearsal)")
+    return ap.parse_args()
+
+
+def cpu_baseline(d_iq, n_cpu, gpu_accepted_in_window):
+    """The reference itself (oracle/_ref, built from /root/reference by
+    oracle/Makefile) timed on one host core over the first n_cpu samples of the
+    same capture.  Falls back to the oracle port when oracle/_ref is absent."""
+    raw = d_iq[:2 * n_cpu].cpu().numpy()
+    ref = os.path.join(ROOT, "oracle", "_ref", "ref_sora_adsb_O2")
+    with tempfile.NamedTemporaryFile(suffix=".uc8", dir="/dev/shm" if
+                                     os.path.isdir("/dev/shm") else None) as tf:
+        raw.tofile(tf)
+        tf.flush()
+        if os.path.exists(ref):
+            with open(tf.name, "rb") as fin:
+                t0 = time.perf_counter()
+                p = subprocess.run([ref, "--adsb-decode", "--adsb-from-raw",
+                                    "--adsb-to-bitstring"], stdin=fin,
+                                   capture_output=True, check=True)
+                dt = time.perf_counter() - t0
+            frames = p.stdout.count(b"\n")
+            kind = "reference"
+            what = "oracle/_ref/ref_sora_adsb_O2 (reference sources, gcc -O2), stdin"
+        else:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_binding as ob
+            t0 = time.perf_counter()
+            frames = len(ob.scan(raw.tobytes(), accepted_only=True, cap=1 << 22))
+            dt = time.perf_counter() - t0
+            kind = "port"
+            what = "oracle/adsb_oracle.c (gcc -O2)"
+    return {
+        "value": round(n_cpu / dt / 1e6, 3), "unit": "Msamples/s", "cores": 1,
+        "kind": kind,
+        "sample": f"first {n_cpu} samples ({n_cpu / 2e6:.0f} s) of the same capture, "
+                  f"{what}, {dt:.1f} s wall",
+        "frames": frames, "gpu_frames_same_window": gpu_accepted_in_window,
+    }
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    import sora_amd
+    from sora_amd import ENC_UC8, FRAME_DTYPE, AdsbContext, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with "
+                         "torch.distributed.run --nproc-per-node N")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1 or args.force_collective:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=dev)              # RCCL over xGMI
+
+    per_gpu = int(args.samples)
+    per_gpu -= per_gpu % 8                                   # shard starts stay 16-byte aligned
+    total = per_gpu * world
+    last = rank == world - 1
+    n_local = per_gpu + (0 if last else sora_amd.HALO)
+
+    # ---- synthetic capture, generated straight into HBM ----
+    params = synth.default_params(2, n_samples=total)
+    frames = synth.make_frames(params)
+    first = rank * per_gpu
+    lo = np.searchsorted(frames["position"], max(0, first - 240))
+    hi = np.searchsorted(frames["position"], first + n_local)
+    d_iq = torch.empty(2 * n_local + 16, dtype=torch.uint8, device=dev)
+    synth.fill_device(d_iq.data_ptr(), n_local, ENC_UC8, params.seed, frames[lo:hi],
+                      first=first)
+    torch.cuda.synchronize()
+
+    max_frames = per_gpu // 1024 + 65536        # ~3x the injected frame rate
+    ctx = AdsbContext(n_local, device=local, max_squitters=max_frames,
+                      max_frames=max_frames)
+    fsz = FRAME_DTYPE.itemsize
+    collective = world > 1 or args.force_collective
+    n_host = max_frames * (world if rank == 0 else 1)
+    h_pin = torch.empty(n_host * fsz, dtype=torch.uint8, pin_memory=True)
+    h_frames = h_pin.numpy().view(FRAME_DTYPE)
+    if collective:
+        d_sq = torch.zeros(max_frames, dtype=torch.int64, device=dev)
+        d_sq_all = torch.zeros(world * max_frames, dtype=torch.int64, device=dev)
+        d_out = torch.zeros(max_frames * fsz, dtype=torch.uint8, device=dev)
+        d_gather = ([torch.zeros_like(d_out) for _ in range(world)] if rank == 0 else None)
+        counts_all = torch.zeros(world, dtype=torch.int64, device=dev)
+
+    scan_ms = []
+
+    def all_counts(k):
+        dist.all_gather_into_tensor(counts_all,
+                                    torch.tensor([k], dtype=torch.int64, device=dev))
+        return [int(x) for x in counts_all.tolist()]
+
+    def step():
+        ctx.reset()                                          # a new capture: no known planes
+        ctx.scan(d_iq, 2 * n_local, ENC_UC8, base_position=first, n_owned=per_gpu)
+        if collective:
+            # the one exchange of the path: clean squitter
+            # records (position << 24 | address, 8 bytes each), all-gathered
+            ks = all_counts(ctx.squitter_count())
+            m = max(ks)
+            if m:
+                ctx.copy_squitters(d_sq, max_frames)
+                ctx.synchronize()
+                dist.all_gather_into_tensor(d_sq_all[:world * m], d_sq[:m])
+                for r in range(world):
+                    if r != rank and ks[r]:
+                        ctx.add_known(d_sq_all[r * m:], ks[r])
+        ctx.resolve()
+        if not collective:
+            n = ctx.collect_into(h_frames)                   # frame list in host memory
+        else:
+            # only the compacted frame lists cross xGMI, gathered to rank 0
+            ns = all_counts(ctx.collect_device(d_out, max_frames))
+            m = max(ns) * fsz
+            if m:
+                dist.gather(d_out[:m], [g[:m] for g in d_gather] if rank == 0 else None,
+                            dst=0)
+            n = sum(ns)
+            if rank == 0:
+                off = 0
+                for r in range(world):
+                    nb = ns[r] * fsz
+                    h_pin[off:off + nb].copy_(d_gather[r][:nb], non_blocking=True)
+                    off += nb
+                torch.cuda.synchronize()
+        scan_ms.append(ctx.last_scan_ms())
+        return n
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        n_frames = step()
+    scan_ms.clear()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        n_frames = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    counts = ctx.counts()
+    kernel_ms = float(np.mean(scan_ms))
+    achieved = n_local * BYTES_PER_SAMPLE / (kernel_ms * 1e-3) / 1e9
+
+    line = {
+        "metric": "Msamples/s ADS-B decoded (2MS/s uc8 IQ)",
+        "value": round(total * args.steps / dt / 1e6, 1),
+        "unit": "Msamples/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u8", "data": "synthetic",
+        "config": {
+            "workload": "configs[1]: 1-hour synthetic 2 MS/s uc8 capture per GPU "
+                        "(DF17/DF11 at mixed SNR), scan + resolve + frame list to host",
+            "samples_per_gpu": per_gpu, "bytes_per_gpu": 2 * n_local,
+            "injected_frames": int(len(frames)), "frames_out": int(n_frames),
+            "candidates_rank0": int(counts["candidates"]),
+        },
+        "roofline": {
+            "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "kernel": "adsb_scan8_kernel", "kernel_ms": round(kernel_ms, 4),
+            "algorithmic_bytes": n_local * BYTES_PER_SAMPLE,
+        },
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu and args.cpu_samples > 0:
+        n_cpu = min(int(args.cpu_samples), per_gpu)
+        pos = h_frames["position"][:n_frames]
+        in_window = int(np.count_nonzero(pos < n_cpu - 239))
+        line["cpu_baseline"] = cpu_baseline(d_iq, n_cpu, in_window)
+    else:
+        line["cpu_baseline"] = None
+
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    ctx.close()
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
