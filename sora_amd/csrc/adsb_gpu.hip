@@ -25,10 +25,13 @@ struct sora_adsb_ctx {
 
     sora_adsb_config cfg;
     uint32_t max_groups;	/* workgroups the scan kernel may use */
+    uint32_t max_regions;	/* accepted regions (sora_filter_regions) */
+    uint32_t cus;
     uint64_t rec_total, sq_total, acc_total, frames_cap;
 
     /* device */
-    uint64_t *d_rec, *d_sq, *d_acc, *d_first_seen, *d_stats;
+    uint64_t *d_rec, *d_sq, *d_acc, *d_acc_flat, *d_first_seen, *d_stats;
+    uint32_t *d_known_bits;
     uint64_t *d_acc_offset, *d_sq_offset;
     uint32_t *d_rec_count, *d_sq_count, *d_acc_count;
     sora_adsb_frame *d_frames;
@@ -36,7 +39,7 @@ struct sora_adsb_ctx {
     size_t stage_bytes;
 
     /* host mirrors */
-    uint32_t *h_counts;		/* 3 * max_groups */
+    uint32_t *h_counts;		/* 2 * max_groups + max_regions */
     uint64_t *h_stats;		/* max_groups * SORA_STAT_WORDS */
     uint64_t h_total[2];
 
@@ -131,6 +134,8 @@ sora_adsb_destroy(sora_adsb_ctx *ctx) {
     (void) hipFree(ctx->d_rec);
     (void) hipFree(ctx->d_sq);
     (void) hipFree(ctx->d_acc);
+    (void) hipFree(ctx->d_acc_flat);
+    (void) hipFree(ctx->d_known_bits);
     (void) hipFree(ctx->d_first_seen);
     (void) hipFree(ctx->d_stats);
     (void) hipFree(ctx->d_acc_offset);
@@ -159,6 +164,8 @@ sora_adsb_reset(sora_adsb_ctx *ctx) {
 	return SORA_ERR_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, sora_launch_fill_u64(ctx->d_first_seen, ~0ull, SORA_ADDRESSES,
+	    ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_known_bits, 0, SORA_ADDRESSES / 8,
 	    ctx->stream));
     ctx->scanned = ctx->resolved = false;
     return SORA_OK;
@@ -204,10 +211,10 @@ sora_adsb_create(sora_adsb_ctx **out, int device, const sora_adsb_config *cfg) {
     HIP_TRY(ctx, hipEventCreate(&ctx->ev_scan_begin));
     HIP_TRY(ctx, hipEventCreate(&ctx->ev_scan_end));
 
-    /* three 41 KB workgroups fit the 160 KB of LDS of a CU */
-    ctx->max_groups = (uint32_t) prop.multiProcessorCount * 3;
-    if (ctx->max_groups == 0)
-	ctx->max_groups = 1;
+    /* three 45 KB workgroups of 512 threads fit the 160 KB of LDS of a CU */
+    ctx->cus = prop.multiProcessorCount > 0? (uint32_t) prop.multiProcessorCount : 1;
+    ctx->max_groups = ctx->cus * 3;
+    ctx->max_regions = sora_filter_regions(ctx->max_groups);
 
     const uint64_t n = cfg->max_chunk_samples;
     ctx->rec_total = cfg->max_candidates != 0? cfg->max_candidates : n / 16 + 65536;
@@ -217,20 +224,23 @@ sora_adsb_create(sora_adsb_ctx **out, int device, const sora_adsb_config *cfg) {
     ctx->frames_cap = ctx->acc_total;
 
     const uint32_t g = ctx->max_groups;
+    const uint32_t nr = ctx->max_regions;
     if (dev_alloc(&ctx->d_rec, ctx->rec_total) != hipSuccess ||
+	    dev_alloc(&ctx->d_acc_flat, ctx->frames_cap) != hipSuccess ||
+	    dev_alloc(&ctx->d_known_bits, SORA_ADDRESSES / 32) != hipSuccess ||
 	    dev_alloc(&ctx->d_sq, ctx->sq_total) != hipSuccess ||
 	    dev_alloc(&ctx->d_acc, ctx->acc_total) != hipSuccess ||
 	    dev_alloc(&ctx->d_frames, ctx->frames_cap) != hipSuccess ||
 	    dev_alloc(&ctx->d_first_seen, SORA_ADDRESSES) != hipSuccess ||
 	    dev_alloc(&ctx->d_stats, (uint64_t) g * SORA_STAT_WORDS) != hipSuccess ||
-	    dev_alloc(&ctx->d_acc_offset, g + 1) != hipSuccess ||
+	    dev_alloc(&ctx->d_acc_offset, nr + 1) != hipSuccess ||
 	    dev_alloc(&ctx->d_sq_offset, g + 1) != hipSuccess ||
 	    dev_alloc(&ctx->d_rec_count, g) != hipSuccess ||
 	    dev_alloc(&ctx->d_sq_count, g) != hipSuccess ||
-	    dev_alloc(&ctx->d_acc_count, g) != hipSuccess)
+	    dev_alloc(&ctx->d_acc_count, nr) != hipSuccess)
 	return fail(ctx, SORA_ERR_NOMEM, "hipMalloc of the device lists failed");
     HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_counts),
-	    3 * (size_t) g * sizeof(uint32_t), hipHostMallocDefault));
+	    (2 * (size_t) g + nr) * sizeof(uint32_t), hipHostMallocDefault));
     HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_stats),
 	    (size_t) g * SORA_STAT_WORDS * sizeof(uint64_t), hipHostMallocDefault));
 
@@ -309,11 +319,14 @@ sora_adsb_scan(sora_adsb_ctx *ctx, const void *d_iq, size_t nbytes, int encoding
     r.sq_count = ctx->d_sq_count;
     r.sq_cap = a.sq_cap;
     r.first_seen = ctx->d_first_seen;
+    r.known_bits = ctx->d_known_bits;
+    r.regions = sora_filter_regions(groups);
     r.acc = ctx->d_acc;
     r.acc_count = ctx->d_acc_count;
-    r.acc_cap = (uint32_t) (ctx->acc_total / groups > 0x7fffffffull?
-	    0x7fffffffull : ctx->acc_total / groups);
+    r.acc_cap = (uint32_t) (ctx->acc_total / r.regions > 0x7fffffffull?
+	    0x7fffffffull : ctx->acc_total / r.regions);
     r.acc_offset = ctx->d_acc_offset;
+    r.acc_flat = ctx->d_acc_flat;
     r.frames = ctx->d_frames;
     r.frames_cap = ctx->frames_cap;
 
@@ -362,7 +375,7 @@ sora_adsb_add_known(sora_adsb_ctx *ctx, const void *d_records, size_t n_records)
     if (ctx == nullptr || (d_records == nullptr && n_records != 0))
 	return SORA_ERR_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, sora_launch_add_known(ctx->d_first_seen,
+    HIP_TRY(ctx, sora_launch_add_known(ctx->d_first_seen, ctx->d_known_bits,
 	    static_cast<const uint64_t *>(d_records), n_records, ctx->stream));
     return SORA_OK;
 }
@@ -377,8 +390,8 @@ sora_adsb_resolve(sora_adsb_ctx *ctx) {
     HIP_TRY(ctx, sora_launch_first_seen(&ctx->res, ctx->stream));
     HIP_TRY(ctx, sora_launch_filter(&ctx->res, ctx->stream));
     HIP_TRY(ctx, sora_launch_scan_counts(ctx->d_acc_count, ctx->res.acc_cap,
-	    ctx->d_acc_offset, ctx->groups, ctx->stream));
-    HIP_TRY(ctx, sora_launch_finalize(&ctx->res, ctx->stream));
+	    ctx->d_acc_offset, ctx->res.regions, ctx->stream));
+    HIP_TRY(ctx, sora_launch_finalize(&ctx->res, ctx->cus, ctx->stream));
     ctx->resolved = true;
     return SORA_OK;
 }
@@ -427,10 +440,11 @@ fetch_counts(sora_adsb_ctx *ctx, bool *overflow) {
 	    g * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_counts + g, ctx->d_sq_count,
 	    g * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    const uint32_t nr = ctx->res.regions;
     if (ctx->resolved) {
 	HIP_TRY(ctx, hipMemcpyAsync(ctx->h_counts + 2 * g, ctx->d_acc_count,
-		g * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-	HIP_TRY(ctx, hipMemcpyAsync(&ctx->h_total[1], ctx->d_acc_offset + g,
+		nr * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(ctx, hipMemcpyAsync(&ctx->h_total[1], ctx->d_acc_offset + nr,
 		sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
     }
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_stats, ctx->d_stats,
@@ -441,8 +455,11 @@ fetch_counts(sora_adsb_ctx *ctx, bool *overflow) {
     *overflow = false;
     for (uint32_t i = 0; i < g; i++) {
 	if (ctx->h_counts[i] > ctx->res.rec_cap ||
-		ctx->h_counts[g + i] > ctx->res.sq_cap ||
-		(ctx->resolved && ctx->h_counts[2 * g + i] > ctx->res.acc_cap))
+		ctx->h_counts[g + i] > ctx->res.sq_cap)
+	    *overflow = true;
+    }
+    for (uint32_t i = 0; ctx->resolved && i < nr; i++) {
+	if (ctx->h_counts[2 * g + i] > ctx->res.acc_cap)
 	    *overflow = true;
     }
     if (ctx->resolved && ctx->h_total[1] > ctx->frames_cap)
@@ -511,11 +528,28 @@ sora_adsb_get_counts(sora_adsb_ctx *ctx, struct sora_adsb_counts *out) {
 	out->squitters += st[SORA_STAT_SQUITTERS];
 	out->dirty_squitters += st[SORA_STAT_DIRTY];
 	out->replies += st[SORA_STAT_REPLIES];
-	if (ctx->resolved)
-	    out->frames += ctx->h_counts[2 * ctx->groups + i];
     }
+    for (uint32_t i = 0; ctx->resolved && i < ctx->res.regions; i++)
+	out->frames += ctx->h_counts[2 * ctx->groups + i];
     return overflow? SORA_ERR_OVERFLOW : SORA_OK;
 }
+
+#ifdef SORA_SCAN_STAMPS
+/* diagnostic build only: sum over workgroups of the 8 phase clocks of wave 0 */
+extern "C" int
+sora_adsb_debug_stamps(sora_adsb_ctx *ctx, uint64_t out[8]) {
+    bool overflow = false;
+    int rc = fetch_counts(ctx, &overflow);
+    if (rc != SORA_OK)
+	return rc;
+    for (int k = 0; k < 8; k++)
+	out[k] = 0;
+    for (uint32_t i = 0; i < ctx->groups; i++)
+	for (int k = 0; k < 8; k++)
+	    out[k] += ctx->h_stats[(size_t) i * SORA_STAT_WORDS + SORA_STAT_WORDS_BASE + k];
+    return SORA_OK;
+}
+#endif
 
 extern "C" int
 sora_adsb_synchronize(sora_adsb_ctx *ctx) {

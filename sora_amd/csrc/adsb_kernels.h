@@ -15,7 +15,12 @@
 #define SORA_STAT_SQUITTERS	1
 #define SORA_STAT_DIRTY		2
 #define SORA_STAT_REPLIES	3
+#define SORA_STAT_WORDS_BASE	4
+#ifdef SORA_SCAN_STAMPS
+#define SORA_STAT_WORDS		12	/* + 8 phase clocks (diagnostic build) */
+#else
 #define SORA_STAT_WORDS		4
+#endif
 
 struct sora_scan_args {
     const uint8_t *iq;		/* device, 16-byte aligned */
@@ -46,10 +51,13 @@ struct sora_resolve_args {
     const uint32_t *sq_count;
     uint32_t sq_cap;
     uint64_t *first_seen;	/* [1 << 24] smallest global position, or ~0 */
-    uint64_t *acc;		/* [groups][acc_cap] accepted records */
-    uint32_t *acc_count;	/* [groups] */
+    uint32_t *known_bits;	/* [1 << 19] bitmap of the addresses in first_seen */
+    uint32_t regions;		/* accepted regions: sora_filter_regions(groups) */
+    uint64_t *acc;		/* [regions][acc_cap] accepted records */
+    uint32_t *acc_count;	/* [regions] */
     uint32_t acc_cap;
-    uint64_t *acc_offset;	/* [groups + 1] exclusive scan of clamped counts */
+    uint64_t *acc_offset;	/* [regions + 1] exclusive scan of clamped counts */
+    uint64_t *acc_flat;		/* [frames_cap] the accepted records, flat */
     struct sora_adsb_frame *frames;
     uint64_t frames_cap;
 };
@@ -67,8 +75,8 @@ hipError_t sora_launch_fill_u64(uint64_t *dst, uint64_t value, uint64_t n,
 hipError_t sora_launch_first_seen(const struct sora_resolve_args *a,
 	hipStream_t stream);
 /* same from flat global records (position << 24 | address) */
-hipError_t sora_launch_add_known(uint64_t *first_seen, const uint64_t *records,
-	uint64_t n, hipStream_t stream);
+hipError_t sora_launch_add_known(uint64_t *first_seen, uint32_t *known_bits,
+	const uint64_t *records, uint64_t n, hipStream_t stream);
 /* squitter lists -> flat global records; offsets = exclusive scan */
 hipError_t sora_launch_export_squitters(const struct sora_resolve_args *a,
 	uint64_t *scan_tmp, uint64_t *dst, uint64_t dst_cap, hipStream_t stream);
@@ -76,7 +84,9 @@ hipError_t sora_launch_filter(const struct sora_resolve_args *a,
 	hipStream_t stream);
 hipError_t sora_launch_scan_counts(const uint32_t *counts, uint32_t cap,
 	uint64_t *offsets, uint32_t n, hipStream_t stream);
-hipError_t sora_launch_finalize(const struct sora_resolve_args *a,
+uint32_t sora_filter_regions(uint32_t groups);
+/* flattens the accepted regions (needs acc_offset) and re-slices the frames */
+hipError_t sora_launch_finalize(const struct sora_resolve_args *a, uint32_t cus,
 	hipStream_t stream);
 hipError_t sora_launch_magnitude(const uint8_t *iq, uint64_t n_samples,
 	int encoding, float *m, hipStream_t stream);

@@ -34,12 +34,28 @@ namespace {
 
 constexpr int kThreads = SORA_TILE_THREADS;
 constexpr int kWaves = kThreads / 64;
+constexpr int kLoads = SORA_TILE_SAMPLES * 2 / 16 / kThreads;	/* 16-byte loads per lane */
+constexpr int kSmall = 256;		/* block size of the list kernels */
 /* the queue (u16 tile-local positions) and the CRC table reuse the M buffer
  * once phase 2 has consumed it */
 constexpr int kQueueMax = SORA_TILE_POS / 2;		/* p and p+1 never both hit */
 constexpr int kCrcTableDword = 4096;			/* past the queue (4032 dwords) */
-static_assert(kQueueMax * 2 <= kCrcTableDword * 4, "queue overlaps CRC table");
-static_assert(kCrcTableDword + 256 <= SORA_M_DWORDS, "CRC table outside M buffer");
+static_assert(kQueueMax * 2 <= kCrcTableDword * 4, "queue overlaps CRC tables");
+static_assert(kCrcTableDword + SORA_CRC_TABLE_WORDS <= SORA_M_DWORDS,
+	"CRC tables outside M buffer");
+constexpr int kCrcCopies = SORA_CRC_TABLE_WORDS / 4;	/* 16-byte pieces of the tables */
+
+/* the sliced CRC tables (adsb_tile.h), built at compile time; every tile
+ * copies them from L2 into the LDS that M has vacated */
+struct crc_slices {
+    uint32_t w[SORA_CRC_TABLE_WORDS];
+    constexpr crc_slices() : w{} {
+	for (int k = 0; k < SORA_CRC_SLICES; k++)
+	    for (uint32_t v = 0; v < 256; v++)
+		w[k * 256 + v] = sora_crc24_slice_entry(k, v);
+    }
+};
+__device__ const crc_slices g_crc_slices = crc_slices();
 
 __device__ __forceinline__ uint32_t
 lane_id() {
@@ -53,25 +69,54 @@ rank_in_mask(unsigned long long mask) {
 	    __builtin_amdgcn_mbcnt_lo((uint32_t) mask, 0));
 }
 
+/* inclusive prefix sum over the 64 lanes of a wave, six DPP adds */
 __device__ __forceinline__ uint32_t
-wave_inclusive_scan(uint32_t v, uint32_t lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-	uint32_t o = __shfl_up(v, d, 64);
-	if (lane >= (uint32_t) d)
-	    v += o;
-    }
+wave_inclusive_scan(uint32_t v) {
+    v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x111, 0xf, 0xf, false);
+    v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x112, 0xf, 0xf, false);
+    v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x114, 0xf, 0xf, false);
+    v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x118, 0xf, 0xf, false);
+    v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x142, 0xa, 0xf, false);
+    v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x143, 0xc, 0xf, false);
     return v;
 }
 
 /* ------------------------------------------------------------------ scan -- */
 
-__global__ void __launch_bounds__(kThreads)
+/*
+ * Diagnostic build only (-DSORA_SCAN_STAMPS, libsora_adsb_gpu_stamps.so): per
+ * phase shader-clock sums of wave 0, stored behind the statistics words.  The
+ * shipped library holds no stamp.
+ */
+#ifdef SORA_SCAN_STAMPS
+#define STAMP_DECL uint64_t st_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint64_t st_last = 0
+#define STAMP_BEGIN() do { __builtin_amdgcn_sched_barrier(0); \
+	st_last = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define STAMP(i) do { __builtin_amdgcn_sched_barrier(0); \
+	uint64_t now_ = __builtin_amdgcn_s_memtime(); \
+	st_t[i] += now_ - st_last; st_last = now_; \
+	__builtin_amdgcn_sched_barrier(0); } while (0)
+#define STAMP_WAIT_VM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define STAMP_WAIT_LDS() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#else
+#define STAMP_DECL
+#define STAMP_BEGIN()
+#define STAMP(i)
+#define STAMP_WAIT_VM()
+#define STAMP_WAIT_LDS()
+#endif
+
+/* 6 waves per SIMD = three 8-wave workgroups per CU (their LDS fits): <= 80 VGPRs */
+__global__ void __launch_bounds__(kThreads, 6)
 adsb_scan8_kernel(sora_scan_args a) {
     __shared__ __attribute__((aligned(16))) uint32_t s_m[SORA_M_DWORDS];
-    __shared__ uint32_t s_nue[SORA_WORDS], s_nuo[SORA_WORDS];
-    __shared__ uint32_t s_de[SORA_WORDS], s_do[SORA_WORDS];
+    /* bit arrays, written as 16-bit halves (one per lane), read as 32-bit words */
+    __shared__ __attribute__((aligned(4))) uint16_t s_nue[2 * SORA_WORDS];
+    __shared__ __attribute__((aligned(4))) uint16_t s_nuo[2 * SORA_WORDS];
+    __shared__ __attribute__((aligned(4))) uint16_t s_de[2 * SORA_WORDS];
+    __shared__ __attribute__((aligned(4))) uint16_t s_do[2 * SORA_WORDS];
     __shared__ uint32_t s_part[kWaves];
+    __shared__ uint32_t s_sq_count;
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63, wave = tid >> 6;
@@ -85,13 +130,17 @@ adsb_scan8_kernel(sora_scan_args a) {
     uint64_t *rec_out = a.rec + (uint64_t) group * a.rec_cap;
     uint64_t *sq_out = a.sq + (uint64_t) group * a.sq_cap;
     uint32_t n_rec = 0, n_sq = 0;		/* workgroup-uniform */
-    uint64_t st_cand = 0, st_sq = 0, st_dirty = 0, st_reply = 0;
+    uint32_t st_cand = 0, st_sq = 0, st_dirty = 0, st_reply = 0;
 
     uint16_t *s_queue = reinterpret_cast<uint16_t *>(s_m);
     uint32_t *s_crc = s_m + kCrcTableDword;
+    STAMP_DECL;
+    const uint32_t *w_nue = reinterpret_cast<const uint32_t *>(s_nue);
+    const uint32_t *w_nuo = reinterpret_cast<const uint32_t *>(s_nuo);
 
     for (uint64_t tile = tile_begin; tile < tile_end; tile++) {
 	const uint64_t tile_start = tile * SORA_TILE_POS;
+	STAMP_BEGIN();
 
 	/* ---- phase 1: load, magnitude, LDS ---- */
 	{
@@ -103,32 +152,37 @@ adsb_scan8_kernel(sora_scan_args a) {
 	    auto rsrc = __builtin_amdgcn_make_buffer_rsrc(
 		    const_cast<uint8_t *>(a.iq) + tile_start * 2, 0, span,
 		    0x00020000);
-	    u32x4 v[8];
+	    u32x4 v[kLoads];
 #pragma unroll
-	    for (int r = 0; r < 8; r++)
+	    for (int r = 0; r < kLoads; r++)
 		v[r] = __builtin_amdgcn_raw_buffer_load_b128(rsrc,
 			(r * kThreads + tid) * 16, 0, 0);
+	    STAMP_WAIT_VM();
+	    STAMP(0);			/* HBM latency of the tile's loads */
 #pragma unroll
-	    for (int r = 0; r < 8; r++) {
+	    for (int r = 0; r < kLoads; r++) {
 		uint32_t pair = (r * kThreads + tid) * 4;
 		u32x4 m;
 		m[0] = sora_mag2_pack8(v[r][0], flip);
 		m[1] = sora_mag2_pack8(v[r][1], flip);
 		m[2] = sora_mag2_pack8(v[r][2], flip);
 		m[3] = sora_mag2_pack8(v[r][3], flip);
-		*reinterpret_cast<u32x4 *>(&s_m[pair + 4 * (pair >> 5)]) = m;
+		*reinterpret_cast<u32x4 *>(&s_m[pair + 4 * (pair >> 4)]) = m;
 	    }
 	    if (tid < 4)
 		s_m[kThreads * SORA_LANE_STRIDE + tid] = 0;
 	}
+	STAMP_WAIT_LDS();
+	STAMP(1);			/* magnitudes + LDS stores */
 	__syncthreads();
+	STAMP(2);			/* barrier 1 */
 
-	/* ---- phase 2: compare words of this lane's 32 pairs ---- */
-	uint32_t nue, nuo, de, dod, ce, co;
+	/* ---- phase 2: compare bits of this lane's 16 pairs ---- */
+	uint32_t up, down, cc;
 	{
 	    uint32_t P[SORA_LANE_STRIDE];
 #pragma unroll
-	    for (int i = 0; i < 8; i++) {
+	    for (int i = 0; i < 4; i++) {
 		u32x4 t = *reinterpret_cast<const u32x4 *>(
 			&s_m[tid * SORA_LANE_STRIDE + 4 * i]);
 		P[4 * i] = t[0]; P[4 * i + 1] = t[1];
@@ -137,43 +191,66 @@ adsb_scan8_kernel(sora_scan_args a) {
 	    {
 		u32x4 t = *reinterpret_cast<const u32x4 *>(
 			&s_m[(tid + 1) * SORA_LANE_STRIDE]);
-		P[32] = t[0]; P[33] = t[1]; P[34] = t[2]; P[35] = t[3];
+		P[16] = t[0]; P[17] = t[1]; P[18] = t[2]; P[19] = t[3];
 	    }
-	    sora_lane_compare(P, &nue, &nuo, &de, &dod, &ce, &co);
+	    sora_lane_compare(P, &up, &down, &cc);
 	}
-	s_nue[tid] = nue;
-	s_nuo[tid] = nuo;
-	s_de[tid] = de;
-	s_do[tid] = dod;
-	if (tid == 0) {
-	    s_nue[kThreads] = 0;
-	    s_nuo[kThreads] = 0;
-	    s_de[kThreads] = 0;
-	    s_do[kThreads] = 0;
+	STAMP(3);			/* LDS reads + compare words */
+	/* lane g is half g of the arrays; MSB first puts even g in the high half
+	 * of a little-endian word, i.e. at 16-bit index g ^ 1 */
+	const uint32_t nue16 = ~up & 0xffffu, nuo16 = (~up) >> 16;
+	const uint32_t de16 = down & 0xffffu, do16 = down >> 16;
+	s_nue[tid ^ 1] = (uint16_t) nue16;
+	s_nuo[tid ^ 1] = (uint16_t) nuo16;
+	s_de[tid ^ 1] = (uint16_t) de16;
+	s_do[tid ^ 1] = (uint16_t) do16;
+	if (tid < 2) {
+	    s_nue[kThreads + tid] = 0;
+	    s_nuo[kThreads + tid] = 0;
+	    s_de[kThreads + tid] = 0;
+	    s_do[kThreads + tid] = 0;
 	}
 	__syncthreads();	/* M is dead from here on: s_m becomes queue + CRC table */
+	STAMP(4);			/* word stores + barrier 2 */
 
 	/* ---- phase 3: predicate words, ordered queue of hits ---- */
+	/* the CRC tables for phase 4: fetched now, stored once the scan is done */
+	u32x4 tab0, tab1 = {0, 0, 0, 0};
+	{
+	    const u32x4 *src = reinterpret_cast<const u32x4 *>(g_crc_slices.w);
+	    tab0 = src[tid];
+	    if (tid + kThreads < kCrcCopies)
+		tab1 = src[tid + kThreads];
+	}
 	uint32_t pe, po;
 	{
-	    uint32_t ve, vo;
-	    uint64_t left = a.n_scan - tile_start;
-	    int64_t limit = left < (uint64_t) SORA_TILE_POS? (int64_t) left
-		    : (int64_t) SORA_TILE_POS;
+	    const uint64_t left = a.n_scan - tile_start;
+	    const uint32_t nx = (tid + 1) ^ 1;	/* the next lane's half */
 
-	    sora_lane_predicate(nue, nuo, de, dod, ce, co,
-		    s_nue[tid + 1], s_nuo[tid + 1], s_de[tid + 1], s_do[tid + 1],
-		    &pe, &po);
-	    sora_lane_valid((int) tid, limit, &ve, &vo);
-	    pe &= ve;
-	    po &= vo;
+	    sora_lane_predicate((nue16 << 16) | s_nue[nx], (nuo16 << 16) | s_nuo[nx],
+		    (de16 << 16) | s_de[nx], (do16 << 16) | s_do[nx],
+		    cc << 16, cc & 0xffff0000u, &pe, &po);
+	    if (left >= (uint64_t) SORA_TILE_POS) {	/* all but the last tile */
+		if (tid >= SORA_OWN_LANES)
+		    pe = po = 0;
+	    } else {
+		uint32_t ve, vo;
+		sora_lane_valid((int) tid, (int64_t) left, &ve, &vo);
+		pe &= ve;
+		po &= vo;
+	    }
 	}
-	s_crc[tid] = sora_crc24_table_entry(tid);
 
-	uint32_t cnt = __popc(pe) + __popc(po);
-	uint32_t incl = wave_inclusive_scan(cnt, lane);
+	const uint32_t cnt = __popc(pe | po);	/* a pair never hits on both
+						 * parities: D[2j] & U[2j+1] vs D[2j+1] */
+	const uint32_t incl = wave_inclusive_scan(cnt);
 	if (lane == 63)
 	    s_part[wave] = incl;
+	*reinterpret_cast<u32x4 *>(&s_crc[4 * tid]) = tab0;
+	if (tid + kThreads < kCrcCopies)
+	    *reinterpret_cast<u32x4 *>(&s_crc[4 * (tid + kThreads)]) = tab1;
+	if (tid == 0)
+	    s_sq_count = 0;
 	__syncthreads();
 	uint32_t total = 0, off = incl - cnt;
 #pragma unroll
@@ -184,7 +261,6 @@ adsb_scan8_kernel(sora_scan_args a) {
 	    total += part;
 	}
 	{
-	    /* a pair never hits on both parities (D[2j] & U[2j+1] vs D[2j+1]) */
 	    uint32_t both = pe | po;
 	    while (both != 0) {
 		uint32_t b = __clz(both);
@@ -195,69 +271,50 @@ adsb_scan8_kernel(sora_scan_args a) {
 	    }
 	}
 	__syncthreads();
+	STAMP(5);			/* predicate, block scan, queue (2 barriers) */
 
-	/* ---- phase 4: one lane per candidate ---- */
+	/* ---- phase 4: one lane per candidate ----
+	 * Every candidate gets the record slot of its queue index, so the
+	 * record list is in position order with no compaction at all (dirty
+	 * squitters ride along; the filter drops them).  Clean squitters, rare,
+	 * are appended to their own list through an LDS counter; that list
+	 * only feeds the first-seen table and needs no order. */
 	st_cand += total;
 	for (uint32_t base = 0; base < total; base += kThreads) {
 	    const uint32_t i = base + tid;
-	    const bool active = i < total;
-	    uint64_t record = 0;
-	    bool want_rec = false, want_sq = false;
 
-	    if (active) {
+	    if (i < total) {
 		uint32_t q = s_queue[i];
-		const uint32_t *words = (q & 1)? s_nuo : s_nue;
+		const uint32_t *words = (q & 1)? w_nuo : w_nue;
 		uint32_t bits[4];
 		sora_candidate c;
 
 		sora_extract_bits(words, (q >> 1) + 8, bits);
 		sora_classify(bits, s_crc, &c);
-		uint64_t kind = !c.squitter? SORA_REC_KIND_REPLY :
+		const uint64_t kind = !c.squitter? SORA_REC_KIND_REPLY :
 			c.syndrome == 0? SORA_REC_KIND_SQUITTER : SORA_REC_KIND_DIRTY;
-		record = sora_rec_make(kind, tile_start + q, c.address);
-		want_sq = kind == SORA_REC_KIND_SQUITTER;
-		want_rec = kind != SORA_REC_KIND_DIRTY || a.emit_all;
-		if (kind == SORA_REC_KIND_DIRTY)
-		    record = sora_rec_make(kind, tile_start + q, c.syndrome);
-		st_sq += want_sq;
+		const uint64_t record = sora_rec_make(kind, tile_start + q,
+			kind == SORA_REC_KIND_DIRTY? c.syndrome : c.address);
+		const uint32_t idx = n_rec + i;
+		if (idx < a.rec_cap)
+		    rec_out[idx] = record;
+		if (kind == SORA_REC_KIND_SQUITTER) {
+		    const uint32_t k = n_sq + atomicAdd(&s_sq_count, 1u);
+		    if (k < a.sq_cap)
+			sq_out[k] = record;
+		}
+		st_sq += kind == SORA_REC_KIND_SQUITTER;
 		st_dirty += kind == SORA_REC_KIND_DIRTY;
 		st_reply += kind == SORA_REC_KIND_REPLY;
 	    }
-
-	    /* ordered block compaction: wave masks, then wave offsets via LDS */
-	    unsigned long long m_rec = __ballot(want_rec);
-	    unsigned long long m_sq = __ballot(want_sq);
-	    if (lane == 0)
-		s_part[wave] = (uint32_t) __popcll(m_rec) |
-			((uint32_t) __popcll(m_sq) << 16);
-	    __syncthreads();
-	    uint32_t pre_rec = 0, pre_sq = 0, tot_rec = 0, tot_sq = 0;
-#pragma unroll
-	    for (int w = 0; w < kWaves; w++) {
-		uint32_t part = s_part[w];
-		if ((uint32_t) w < wave) {
-		    pre_rec += part & 0xffffu;
-		    pre_sq += part >> 16;
-		}
-		tot_rec += part & 0xffffu;
-		tot_sq += part >> 16;
-	    }
-	    if (want_rec) {
-		uint32_t idx = n_rec + pre_rec + rank_in_mask(m_rec);
-		if (idx < a.rec_cap)
-		    rec_out[idx] = record;
-	    }
-	    if (want_sq) {
-		uint32_t idx = n_sq + pre_sq + rank_in_mask(m_sq);
-		if (idx < a.sq_cap)
-		    sq_out[idx] = record;
-	    }
-	    n_rec += tot_rec;
-	    n_sq += tot_sq;
-	    __syncthreads();
 	}
+	n_rec += total;
+	__syncthreads();
+	n_sq += s_sq_count;
 	/* every lane has passed a barrier after its last read of the queue,
-	 * the CRC table and the NU arrays, so the next tile may refill them */
+	 * the CRC tables and the NU arrays, so the next tile may refill them;
+	 * s_sq_count is rewritten only behind the next tile's barriers */
+	STAMP(6);			/* candidates: extract, CRC, records */
     }
 
     /* per-workgroup results */
@@ -265,16 +322,16 @@ adsb_scan8_kernel(sora_scan_args a) {
 	a.rec_count[group] = n_rec;
 	a.sq_count[group] = n_sq;
     }
-    /* statistics: cand is workgroup-uniform, the others per lane */
+    /* statistics: st_cand is workgroup-uniform, the others per lane */
     {
-	uint64_t v1 = st_sq, v2 = st_dirty, v3 = st_reply;
+	uint32_t v1 = st_sq, v2 = st_dirty, v3 = st_reply;
 #pragma unroll
 	for (int d = 32; d >= 1; d >>= 1) {
 	    v1 += __shfl_xor(v1, d, 64);
 	    v2 += __shfl_xor(v2, d, 64);
 	    v3 += __shfl_xor(v3, d, 64);
 	}
-	__shared__ uint64_t s_stat[kWaves][3];
+	__shared__ uint32_t s_stat[kWaves][3];
 	if (lane == 0) {
 	    s_stat[wave][0] = v1;
 	    s_stat[wave][1] = v2;
@@ -293,6 +350,10 @@ adsb_scan8_kernel(sora_scan_args a) {
 	    st[SORA_STAT_SQUITTERS] = t1;
 	    st[SORA_STAT_DIRTY] = t2;
 	    st[SORA_STAT_REPLIES] = t3;
+#ifdef SORA_SCAN_STAMPS
+	    for (int i = 0; i < 8; i++)
+		st[SORA_STAT_WORDS_BASE + i] = st_t[i];
+#endif
 	}
     }
 }
@@ -308,6 +369,24 @@ fill_u64_kernel(uint64_t *dst, uint64_t value, uint64_t n) {
 	dst[i] = value;
 }
 
+/*
+ * Known addresses: first_seen[A] = smallest global position of an accepted
+ * DF11/17/18 frame from A (64-bit, 128 MiB, touched sparsely) and a 2 MiB
+ * bitmap of the same set that stays in L2 for the filter's random lookups.
+ * The plain pre-check is only a shortcut: first_seen values never grow, so a
+ * stale read can cost an atomic, never skip a needed one.
+ */
+__device__ __forceinline__ void
+note_known(uint64_t *first_seen, uint32_t *known_bits, uint32_t addr,
+	uint64_t position) {
+    if (first_seen[addr] > position)
+	atomicMin(reinterpret_cast<unsigned long long *>(&first_seen[addr]),
+		(unsigned long long) position);
+    const uint32_t bit = 1u << (addr & 31);
+    if ((known_bits[addr >> 5] & bit) == 0)
+	atomicOr(&known_bits[addr >> 5], bit);
+}
+
 /* one block per workgroup region of the scan */
 __global__ void
 first_seen_kernel(sora_resolve_args a) {
@@ -319,22 +398,20 @@ first_seen_kernel(sora_resolve_args a) {
 	n = a.sq_cap;
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
 	uint64_t r = sq[i];
-	atomicMin(reinterpret_cast<unsigned long long *>(
-		&a.first_seen[sora_rec_addr(r)]),
-		(unsigned long long) (a.base_position + sora_rec_pos(r)));
+	note_known(a.first_seen, a.known_bits, sora_rec_addr(r),
+		a.base_position + sora_rec_pos(r));
     }
 }
 
 __global__ void
-add_known_kernel(uint64_t *first_seen, const uint64_t *records, uint64_t n) {
+add_known_kernel(uint64_t *first_seen, uint32_t *known_bits,
+	const uint64_t *records, uint64_t n) {
     uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t stride = (uint64_t) gridDim.x * blockDim.x;
 
     for (; i < n; i += stride) {
 	uint64_t r = records[i];
-	atomicMin(reinterpret_cast<unsigned long long *>(
-		&first_seen[(uint32_t) r & 0xffffffu]),
-		(unsigned long long) (r >> 24));
+	note_known(first_seen, known_bits, (uint32_t) r & 0xffffffu, r >> 24);
     }
 }
 
@@ -402,67 +479,87 @@ export_squitters_kernel(sora_resolve_args a, const uint64_t *offsets,
 
 /*
  * The stateful rule of plane.c:479-483 as a pure function: a reply at global
- * position P with address A is accepted iff first_seen[A] < P.  Order
- * preserving compaction of each region into the accepted list.
+ * position P with address A is accepted iff first_seen[A] < P.  Each wave
+ * takes a contiguous quarter of one scan region and compacts it, in order,
+ * into an accepted region of its own (region = 4 * group + wave): no
+ * barriers, four independent record loads in flight per lane.
  */
-__global__ void __launch_bounds__(kThreads)
+constexpr int kFilterWaves = kSmall / 64;
+constexpr int kFilterUnroll = 4;
+
+__global__ void __launch_bounds__(kSmall)
 filter_kernel(sora_resolve_args a) {
-    __shared__ uint32_t s_part[kWaves];
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t group = blockIdx.x;
+    const uint32_t region = group * kFilterWaves + wave;
     const uint64_t *rec = a.rec + (uint64_t) group * a.rec_cap;
-    uint64_t *acc = a.acc + (uint64_t) group * a.acc_cap;
+    uint64_t *acc = a.acc + (uint64_t) region * a.acc_cap;
     uint32_t n = a.rec_count[group];
     uint32_t n_acc = 0;
 
     if (n > a.rec_cap)
 	n = a.rec_cap;
-    for (uint32_t base = 0; base < n; base += kThreads) {
-	const uint32_t i = base + tid;
-	bool keep = false;
-	uint64_t r = 0;
+    const uint32_t begin = (uint32_t) ((uint64_t) n * wave / kFilterWaves);
+    const uint32_t end = (uint32_t) ((uint64_t) n * (wave + 1) / kFilterWaves);
 
-	if (i < n) {
-	    r = rec[i];
-	    uint32_t kind = sora_rec_kind(r);
-	    if (kind == SORA_REC_KIND_SQUITTER) {
-		keep = true;
-		r |= SORA_REC_ACCEPTED << 60;
-	    } else if (kind == SORA_REC_KIND_REPLY) {
-		bool known = a.first_seen[sora_rec_addr(r)] <
-			a.base_position + sora_rec_pos(r);
-		if (known)
-		    r |= SORA_REC_ACCEPTED << 60;
-		keep = known || a.emit_all;
-	    } else {
-		keep = a.emit_all != 0;
+    for (uint32_t base = begin; base < end; base += 64 * kFilterUnroll) {
+	uint64_t r[kFilterUnroll];
+	bool keep[kFilterUnroll];
+#pragma unroll
+	for (int u = 0; u < kFilterUnroll; u++) {
+	    const uint32_t i = base + u * 64 + lane;
+	    r[u] = i < end? rec[i] : ~0ull;
+	}
+#pragma unroll
+	for (int u = 0; u < kFilterUnroll; u++) {
+	    const uint32_t i = base + u * 64 + lane;
+	    const uint32_t kind = sora_rec_kind(r[u]);
+	    keep[u] = false;
+	    if (i < end) {
+		if (kind == SORA_REC_KIND_SQUITTER) {
+		    keep[u] = true;
+		    r[u] |= SORA_REC_ACCEPTED << 60;
+		} else if (kind == SORA_REC_KIND_REPLY) {
+		    const uint32_t addr = sora_rec_addr(r[u]);
+		    bool known = (a.known_bits[addr >> 5] >> (addr & 31)) & 1;
+		    if (known)
+			known = a.first_seen[addr] < a.base_position + sora_rec_pos(r[u]);
+		    if (known)
+			r[u] |= SORA_REC_ACCEPTED << 60;
+		    keep[u] = known || a.emit_all;
+		} else {
+		    keep[u] = a.emit_all != 0;
+		}
 	    }
 	}
-	/* survivors are rare: most rounds keep nothing (workgroup-uniform test) */
-	if (__syncthreads_or(keep) == 0)
-	    continue;
-	unsigned long long m = __ballot(keep);
-	if (lane == 0)
-	    s_part[wave] = (uint32_t) __popcll(m);
-	__syncthreads();
-	uint32_t pre = 0, tot = 0;
 #pragma unroll
-	for (int w = 0; w < kWaves; w++) {
-	    uint32_t part = s_part[w];
-	    if ((uint32_t) w < wave)
-		pre += part;
-	    tot += part;
+	for (int u = 0; u < kFilterUnroll; u++) {
+	    const unsigned long long m = __ballot(keep[u]);
+	    if (keep[u]) {
+		const uint32_t idx = n_acc + rank_in_mask(m);
+		if (idx < a.acc_cap)
+		    acc[idx] = r[u];
+	    }
+	    n_acc += (uint32_t) __popcll(m);
 	}
-	if (keep) {
-	    uint32_t idx = n_acc + pre + rank_in_mask(m);
-	    if (idx < a.acc_cap)
-		acc[idx] = r;
-	}
-	n_acc += tot;
-	__syncthreads();
     }
-    if (tid == 0)
-	a.acc_count[group] = n_acc;
+    if (lane == 0)
+	a.acc_count[region] = n_acc;
+}
+
+/* accepted regions -> one flat, position-sorted list */
+__global__ void __launch_bounds__(kSmall)
+flatten_kernel(sora_resolve_args a) {
+    const uint32_t region = blockIdx.x;
+    const uint64_t *acc = a.acc + (uint64_t) region * a.acc_cap;
+    uint32_t n = a.acc_count[region];
+    const uint64_t off = a.acc_offset[region];
+
+    if (n > a.acc_cap)
+	n = a.acc_cap;
+    for (uint32_t i = threadIdx.x; i < n; i += kSmall)
+	if (off + i < a.frames_cap)
+	    a.acc_flat[off + i] = acc[i];
 }
 
 /* x^n mod G for n = 0..111, G = 0x1FFF409: the CRC contribution of one bit */
@@ -500,94 +597,124 @@ magnitude_f32(const uint8_t *iq, uint64_t i, int encoding) {
     return (float) (vi * vi + vq * vq) * (1.0f / 16384.0f);
 }
 
+/* the 4 magnitudes a lane needs of one frame: samples s+2*lane(+1), s+128+2*lane(+1) */
+struct frame_mags {
+    float a0, a1, b0, b1;
+};
+
+__device__ __forceinline__ frame_mags
+load_frame_mags(const uint8_t *iq, uint64_t p, uint32_t lane, int encoding) {
+    frame_mags m;
+    const uint64_t s = p + 16;
+    m.a0 = magnitude_f32(iq, s + 2 * lane, encoding);
+    m.a1 = magnitude_f32(iq, s + 2 * lane + 1, encoding);
+    m.b0 = 0;
+    m.b1 = 1;
+    if (lane < 48) {
+	m.b0 = magnitude_f32(iq, s + 128 + 2 * lane, encoding);
+	m.b1 = magnitude_f32(iq, s + 128 + 2 * lane + 1, encoding);
+    }
+    return m;
+}
+
 /*
  * Re-slices every accepted position from the raw samples in HBM, one wave
  * per frame: the independent second implementation of the slicer
  * (plane-iq.c:58-86) and of the CRC (plane.c:373-385), and the only place
  * amplitudes are computed (only accepted frames need them).
  */
-__global__ void __launch_bounds__(kThreads)
-finalize_kernel(sora_resolve_args a) {
-    __shared__ float s_amp[kWaves][56];
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t group = blockIdx.x;
-    const uint64_t *acc = a.acc + (uint64_t) group * a.acc_cap;
-    uint32_t n = a.acc_count[group];
-    const uint64_t out0 = a.acc_offset[group];
+__device__ __forceinline__ void
+finalize_one(const sora_resolve_args &a, uint64_t f, uint64_t r, const frame_mags &m,
+	uint32_t lane, float *s_amp) {
+    const uint64_t p = sora_rec_pos(r);
 
-    if (n > a.acc_cap)
-	n = a.acc_cap;
-    for (uint32_t i = wave; i < n; i += kWaves) {
-	const uint64_t r = acc[i];
-	const uint64_t p = sora_rec_pos(r);
-	const uint64_t s = p + 16;
+    /* bit k = m[p+17+2k] <= m[p+16+2k], k = lane and k = 64 + lane */
+    unsigned long long lo = __ballot(m.a1 <= m.a0);
+    unsigned long long hi = __ballot(lane < 48 && m.b1 <= m.b0);
+    uint32_t bits[4];
+    bits[0] = __brev((uint32_t) lo);
+    bits[1] = __brev((uint32_t) (lo >> 32));
+    bits[2] = __brev((uint32_t) hi);
+    bits[3] = __brev((uint32_t) (hi >> 32)) & 0xffff0000u;
 
-	/* bit k = m[p+17+2k] <= m[p+16+2k], k = lane and k = 64 + lane */
-	float a0 = magnitude_f32(a.iq, s + 2 * lane, a.encoding);
-	float a1 = magnitude_f32(a.iq, s + 2 * lane + 1, a.encoding);
-	float b0 = 0, b1 = 1;
-	if (lane < 48) {
-	    b0 = magnitude_f32(a.iq, s + 128 + 2 * lane, a.encoding);
-	    b1 = magnitude_f32(a.iq, s + 128 + 2 * lane + 1, a.encoding);
-	}
-	unsigned long long lo = __ballot(a1 <= a0);
-	unsigned long long hi = __ballot(lane < 48 && b1 <= b0);
-	uint32_t bits[4];
-	bits[0] = __brev((uint32_t) lo);
-	bits[1] = __brev((uint32_t) (lo >> 32));
-	bits[2] = __brev((uint32_t) hi);
-	bits[3] = __brev((uint32_t) (hi >> 32)) & 0xffff0000u;
+    /* plane.c:461-475 */
+    const uint32_t df = bits[0] >> 27;
+    const bool is_long = df >= 16 && df <= 24;
+    const int covered = is_long? 88 : 32;
+    uint32_t x = 0;
+    if ((int) lane < covered && ((lo >> lane) & 1))
+	x = c_crc_pow.r[covered + 23 - lane];
+    if ((int) lane + 64 < covered && ((hi >> lane) & 1))
+	x ^= c_crc_pow.r[covered + 23 - 64 - lane];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1)
+	x ^= __shfl_xor(x, d, 64);
+    const uint32_t ap = is_long? (((bits[2] & 0xffu) << 16) | (bits[3] >> 16))
+	    : (bits[1] >> 8);
+    const uint32_t syndrome = x ^ ap;
+    const bool squitter = df == 11 || df == 17 || df == 18;
 
-	/* plane.c:461-475 */
-	const uint32_t df = bits[0] >> 27;
-	const bool is_long = df >= 16 && df <= 24;
-	const int covered = is_long? 88 : 32;
-	uint32_t x = 0;
-	if ((int) lane < covered && ((lo >> lane) & 1))
-	    x = c_crc_pow.r[covered + 23 - lane];
-	if ((int) lane + 64 < covered && ((hi >> lane) & 1))
-	    x ^= c_crc_pow.r[covered + 23 - 64 - lane];
+    /* plane-iq.c:62-73: float (s0+s1)/2 accumulated in double, in order */
+    if (lane < 56)
+	s_amp[lane] = __fmul_rn(__fadd_rn(m.a0, m.a1), 0.5f);
+    uint32_t sum56 = 0;
+    if (a.encoding != SORA_ENC_SC16) {
+	/* integers: M = m * 2^14 exactly */
+	sum56 = lane < 56? (uint32_t) (__fadd_rn(m.a0, m.a1) * 16384.0f) : 0;
 #pragma unroll
 	for (int d = 32; d >= 1; d >>= 1)
-	    x ^= __shfl_xor(x, d, 64);
-	const uint32_t ap = is_long? (((bits[2] & 0xffu) << 16) | (bits[3] >> 16))
-		: (bits[1] >> 8);
-	const uint32_t syndrome = x ^ ap;
-	const bool squitter = df == 11 || df == 17 || df == 18;
-
-	/* plane-iq.c:62-73: float (s0+s1)/2 accumulated in double, in order */
-	if (lane < 56)
-	    s_amp[wave][lane] = __fmul_rn(__fadd_rn(a0, a1), 0.5f);
-	uint32_t sum56 = 0;
+	    sum56 += __shfl_xor(sum56, d, 64);
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+	double a56;
 	if (a.encoding != SORA_ENC_SC16) {
-	    /* integers: M = m * 2^14 exactly */
-	    sum56 = lane < 56? (uint32_t) (__fadd_rn(a0, a1) * 16384.0f) : 0;
-#pragma unroll
-	    for (int d = 32; d >= 1; d >>= 1)
-		sum56 += __shfl_xor(sum56, d, 64);
-	}
-	__builtin_amdgcn_wave_barrier();
-	if (lane == 0 && out0 + i < a.frames_cap) {
-	    double a56 = 0;
+	    a56 = (double) sum56 * (1.0 / 32768.0);	/* exact: see sora_adsb_frame */
+	} else {
+	    a56 = 0;
 	    for (int k = 0; k < 56; k++)
-		a56 += (double) s_amp[wave][k];
-	    sora_adsb_frame f;
-	    f.position = a.base_position + p;
-	    f.bits[0] = bits[0]; f.bits[1] = bits[1];
-	    f.bits[2] = bits[2]; f.bits[3] = bits[3];
-	    f.amplitude_56 = a56;
-	    f.syndrome = syndrome;
-	    f.address = squitter? (bits[0] & 0xffffffu) : syndrome;
-	    f.sum56 = sum56;
-	    f.df = (uint8_t) df;
-	    f.corrected_bit = -1;
-	    f.flags = (uint8_t) ((is_long? SORA_FRAME_LONG : 0) |
-		    (squitter? SORA_FRAME_SQUITTER : 0) |
-		    ((sora_rec_kind(r) & SORA_REC_ACCEPTED)? SORA_FRAME_ACCEPTED : 0));
-	    f.reserved = 0;
-	    a.frames[out0 + i] = f;
+		a56 += (double) s_amp[k];
 	}
-	__builtin_amdgcn_wave_barrier();
+	sora_adsb_frame fr;
+	fr.position = a.base_position + p;
+	fr.bits[0] = bits[0]; fr.bits[1] = bits[1];
+	fr.bits[2] = bits[2]; fr.bits[3] = bits[3];
+	fr.amplitude_56 = a56;
+	fr.syndrome = syndrome;
+	fr.address = squitter? (bits[0] & 0xffffffu) : syndrome;
+	fr.sum56 = sum56;
+	fr.df = (uint8_t) df;
+	fr.corrected_bit = -1;
+	fr.flags = (uint8_t) ((is_long? SORA_FRAME_LONG : 0) |
+		(squitter? SORA_FRAME_SQUITTER : 0) |
+		((sora_rec_kind(r) & SORA_REC_ACCEPTED)? SORA_FRAME_ACCEPTED : 0));
+	fr.reserved = 0;
+	a.frames[f] = fr;
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+__global__ void __launch_bounds__(kSmall)
+finalize_kernel(sora_resolve_args a) {
+    __shared__ float s_amp[kSmall / 64][56];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t n_waves = (uint64_t) gridDim.x * (kSmall / 64);
+    const uint64_t gw = (uint64_t) blockIdx.x * (kSmall / 64) + wave;
+    uint64_t total = a.acc_offset[a.regions];
+
+    if (total > a.frames_cap)
+	total = a.frames_cap;
+    /* two frames per trip so that both sample fetches are in flight together */
+    for (uint64_t f = gw; f < total; f += 2 * n_waves) {
+	const uint64_t g = f + n_waves;
+	const bool two = g < total;
+	const uint64_t r0 = a.acc_flat[f];
+	const uint64_t r1 = two? a.acc_flat[g] : r0;
+	const frame_mags m0 = load_frame_mags(a.iq, sora_rec_pos(r0), lane, a.encoding);
+	const frame_mags m1 = load_frame_mags(a.iq, sora_rec_pos(r1), lane, a.encoding);
+	finalize_one(a, f, r0, m0, lane, s_amp[wave]);
+	if (two)
+	    finalize_one(a, g, r1, m1, lane, s_amp[wave]);
     }
 }
 
@@ -619,8 +746,7 @@ sora_scan_tiles(uint64_t n_scan, int encoding) {
 uint32_t
 sora_scan_lds_bytes(int encoding) {
     (void) encoding;
-    return (uint32_t) ((SORA_M_DWORDS + 4 * SORA_WORDS + kWaves) * 4 +
-	    kWaves * 3 * 8);
+    return (uint32_t) ((SORA_M_DWORDS + 4 * SORA_WORDS + kWaves + kWaves * 3) * 4);
 }
 
 hipError_t
@@ -635,25 +761,25 @@ sora_launch_scan(const sora_scan_args *a, uint32_t groups, hipStream_t stream) {
 hipError_t
 sora_launch_fill_u64(uint64_t *dst, uint64_t value, uint64_t n,
 	hipStream_t stream) {
-    hipLaunchKernelGGL(fill_u64_kernel, dim3(grid_for(n, 256)), dim3(256), 0,
+    hipLaunchKernelGGL(fill_u64_kernel, dim3(grid_for(n, 1024)), dim3(256), 0,
 	    stream, dst, value, n);
     return hipGetLastError();
 }
 
 hipError_t
 sora_launch_first_seen(const sora_resolve_args *a, hipStream_t stream) {
-    hipLaunchKernelGGL(first_seen_kernel, dim3(a->groups), dim3(256), 0, stream,
-	    *a);
+    hipLaunchKernelGGL(first_seen_kernel, dim3(a->groups), dim3(kSmall), 0,
+	    stream, *a);
     return hipGetLastError();
 }
 
 hipError_t
-sora_launch_add_known(uint64_t *first_seen, const uint64_t *records,
-	uint64_t n, hipStream_t stream) {
+sora_launch_add_known(uint64_t *first_seen, uint32_t *known_bits,
+	const uint64_t *records, uint64_t n, hipStream_t stream) {
     if (n == 0)
 	return hipSuccess;
     hipLaunchKernelGGL(add_known_kernel, dim3(grid_for(n, 256)), dim3(256), 0,
-	    stream, first_seen, records, n);
+	    stream, first_seen, known_bits, records, n);
     return hipGetLastError();
 }
 
@@ -679,15 +805,26 @@ sora_launch_export_squitters(const sora_resolve_args *a, uint64_t *scan_tmp,
 
 hipError_t
 sora_launch_filter(const sora_resolve_args *a, hipStream_t stream) {
-    hipLaunchKernelGGL(filter_kernel, dim3(a->groups), dim3(kThreads), 0,
-	    stream, *a);
+    hipLaunchKernelGGL(filter_kernel, dim3(a->groups), dim3(kSmall), 0, stream,
+	    *a);
     return hipGetLastError();
 }
 
+uint32_t
+sora_filter_regions(uint32_t groups) {
+    return groups * kFilterWaves;
+}
+
 hipError_t
-sora_launch_finalize(const sora_resolve_args *a, hipStream_t stream) {
-    hipLaunchKernelGGL(finalize_kernel, dim3(a->groups), dim3(kThreads), 0,
-	    stream, *a);
+sora_launch_finalize(const sora_resolve_args *a, uint32_t cus, hipStream_t stream) {
+    hipLaunchKernelGGL(flatten_kernel, dim3(a->regions), dim3(kSmall), 0, stream,
+	    *a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess)
+	return e;
+    /* 8 blocks of 4 waves per CU: every wave slot busy hiding the two
+     * dependent fetches (record, then samples) of a frame */
+    hipLaunchKernelGGL(finalize_kernel, dim3(cus * 8), dim3(kSmall), 0, stream, *a);
     return hipGetLastError();
 }
 

@@ -20,7 +20,8 @@
  *
  * Bit arrays are split by parity (E: even positions, O: odd) and packed
  * MSB first: element j of an array is bit 31-(j%32) of word j/32, so that a
- * message read out of them has bit 0 (the first DF bit) on top.
+ * message read out of them has bit 0 (the first DF bit) on top.  A lane
+ * produces 16 elements of each array (one 16-bit half word).
  */
 #ifndef SORA_ADSB_TILE_H_
 #define SORA_ADSB_TILE_H_
@@ -34,18 +35,20 @@
 #endif
 
 /* ---- tile geometry for the 8-bit encodings ---- */
-#define SORA_TILE_THREADS	256
-#define SORA_LANE_PAIRS		32		/* pairs (dwords of M) per lane */
-#define SORA_LANE_POS		64		/* positions per lane */
-#define SORA_OWN_LANES		252		/* lanes whose positions a tile owns */
+#define SORA_TILE_THREADS	512
+#define SORA_LANE_PAIRS		16		/* pairs (dwords of M) per lane */
+#define SORA_LANE_POS		32		/* positions per lane */
+#define SORA_OWN_LANES		504		/* lanes whose positions a tile owns */
 #define SORA_TILE_POS		(SORA_OWN_LANES * SORA_LANE_POS)	/* 16128 */
 #define SORA_TILE_SAMPLES	(SORA_TILE_THREADS * SORA_LANE_POS)	/* 16384 */
-/* M in LDS: lane g's 32 dwords start at dword 36*g (4 dwords of padding keep
+/* M in LDS: lane g's 16 dwords start at dword 20*g (4 dwords of padding keep
  * both the 16-byte stores of the load phase and the 16-byte reads of the
- * compare phase bank-conflict free) */
-#define SORA_LANE_STRIDE	36
+ * compare phase bank-conflict free: 20 = 4*5, 5 odd) */
+#define SORA_LANE_STRIDE	20
 #define SORA_M_DWORDS		(SORA_TILE_THREADS * SORA_LANE_STRIDE + 4)
-#define SORA_WORDS		(SORA_TILE_THREADS + 1)	/* bit-array words + 1 */
+/* bit arrays: one 16-bit half word per lane, +1 word of lookahead; as 32-bit
+ * words, MSB first: lane 2w is the top half of word w */
+#define SORA_WORDS		(SORA_TILE_THREADS / 2 + 1)
 
 #define SORA_WINDOW		240
 
@@ -84,50 +87,104 @@ sora_mag2_pack8(uint32_t iq, uint32_t flip) {
     return m0 | (m1 << 16);		/* each <= 32768 */
 }
 
-/* ---- a3/a5 on one lane's run of 32 pairs ---- */
+/* ---- packed 16-bit arithmetic: one VALU instruction per pair on gfx950 ---- */
 
+/* per half: a - b, saturating at 0 (v_pk_sub_u16 ... clamp) */
+SORA_HD uint32_t
+sora_pk_sub_sat(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t r;
+    asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#else
+    uint32_t al = a & 0xffffu, ah = a >> 16, bl = b & 0xffffu, bh = b >> 16;
+    return (al > bl? al - bl : 0) | ((ah > bh? ah - bh : 0) << 16);
+#endif
+}
+
+SORA_HD uint32_t
+sora_pk_min(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t r;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#else
+    uint32_t al = a & 0xffffu, ah = a >> 16, bl = b & 0xffffu, bh = b >> 16;
+    return (al < bl? al : bl) | ((ah < bh? ah : bh) << 16);
+#endif
+}
+
+SORA_HD uint32_t
+sora_pk_max(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t r;
+    asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#else
+    uint32_t al = a & 0xffffu, ah = a >> 16, bl = b & 0xffffu, bh = b >> 16;
+    return (al > bl? al : bl) | ((ah > bh? ah : bh) << 16);
+#endif
+}
+
+/* [M[2j+1], M[2j+2]] from pairs j and j+1 */
+SORA_HD uint32_t
+sora_pair_shift(uint32_t p, uint32_t pn) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbit(pn, p, 16);
+#else
+    return (p >> 16) | (pn << 16);
+#endif
+}
+
+/* ---- a3/a5 on one lane's run of 16 pairs ---- */
 
 /*
- * P[0..35]: the lane's 32 dwords of packed M followed by the next lane's
- * first 4 (only 3 are used).  Element b of each result word (bit 31-b) is
- * pair b of the lane.
+ * P[0..19]: the lane's 16 dwords of packed M followed by the next lane's
+ * first 4.  Each result holds the EVEN positions in its low half and the ODD
+ * positions in its high half; within a half, pair s of the lane is bit 15-s.
+ *   up   M[i+1] >  M[i]		(NU = ~up is the slicer bit, plane-iq.c:65)
+ *   down M[i+1] <  M[i]
+ *   c    M[i] > max(M[i+4], M[i+5], M[i+6])
+ * 12 VALU instructions per pair for both parities.
  */
 SORA_HD void
-sora_lane_compare(const uint32_t *P, uint32_t *nue, uint32_t *nuo,
-	uint32_t *de, uint32_t *dod, uint32_t *ce, uint32_t *co) {
-    uint32_t w_nue = 0, w_nuo = 0, w_de = 0, w_do = 0, w_ce = 0, w_co = 0;
+sora_lane_compare(const uint32_t *P, uint32_t *up, uint32_t *down, uint32_t *c) {
+    const uint32_t one = 0x00010001u;
+    uint32_t S[SORA_LANE_PAIRS + 3];
+    uint32_t W[SORA_LANE_PAIRS + 2];
+    uint32_t acc_u = 0, acc_d = 0, acc_c = 0;
 
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
+    for (int s = 0; s < SORA_LANE_PAIRS + 3; s++)
+	S[s] = sora_pair_shift(P[s], P[s + 1]);
+    /* W[s] = [max M[2s..2s+2], max M[2s+1..2s+3]] */
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int s = 2; s < SORA_LANE_PAIRS + 2; s++)
+	W[s] = sora_pk_max(sora_pk_max(P[s], S[s]), P[s + 1]);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
     for (int s = 0; s < SORA_LANE_PAIRS; s++) {
-	uint32_t a_lo = P[s] & 0xffffu, a_hi = P[s] >> 16;
-	uint32_t b_lo = P[s + 1] & 0xffffu;
-	uint32_t c_lo = P[s + 2] & 0xffffu, c_hi = P[s + 2] >> 16;
-	uint32_t d_lo = P[s + 3] & 0xffffu, d_hi = P[s + 3] >> 16;
-	uint32_t mid = c_hi > d_lo? c_hi : d_lo;
-	uint32_t mx_e = c_lo > mid? c_lo : mid;	/* max M[2j+4..2j+6] */
-	uint32_t mx_o = d_hi > mid? d_hi : mid;	/* max M[2j+5..2j+7] */
-
-	w_nue = (w_nue << 1) | (uint32_t) (a_hi <= a_lo);
-	w_de  = (w_de  << 1) | (uint32_t) (a_hi <  a_lo);
-	w_nuo = (w_nuo << 1) | (uint32_t) (b_lo <= a_hi);
-	w_do  = (w_do  << 1) | (uint32_t) (b_lo <  a_hi);
-	w_ce  = (w_ce  << 1) | (uint32_t) (a_lo > mx_e);
-	w_co  = (w_co  << 1) | (uint32_t) (a_hi > mx_o);
+	uint32_t u = sora_pk_min(sora_pk_sub_sat(S[s], P[s]), one);
+	uint32_t d = sora_pk_min(sora_pk_sub_sat(P[s], S[s]), one);
+	uint32_t k = sora_pk_min(sora_pk_sub_sat(P[s], W[s + 2]), one);
+	acc_u |= u << (15 - s);
+	acc_d |= d << (15 - s);
+	acc_c |= k << (15 - s);
     }
-    *nue = w_nue; *nuo = w_nuo; *de = w_de; *dod = w_do; *ce = w_ce; *co = w_co;
-}
-
-/* element j+k of an MSB-first bit array, aligned onto element j;
- * x: this word, xn: the next word; 1 <= k <= 31 */
-SORA_HD uint32_t
-sora_ahead(uint32_t x, uint32_t xn, int k) {
-    return (x << k) | (xn >> (32 - k));
+    *up = acc_u;
+    *down = acc_d;
+    *c = acc_c;
 }
 
 /*
- * Candidate masks of one lane from its own words and the next lane's.
+ * Candidate masks of one lane.  Arguments are 32-bit windows of the MSB-first
+ * bit arrays: the lane's own 16 elements in the top half, the next lane's 16
+ * below them; results are valid in the top half.
  * Even p = 2j:   D[2j] & U[2j+1] & D[2j+2] & D[2j+7] & U[2j+8] & C[2j]
  *              = DE[j] & !NUO[j] & DE[j+1] & DO[j+3] & !NUE[j+4] & CE[j]
  * Odd p = 2j+1:  D[2j+1] & U[2j+2] & D[2j+3] & D[2j+8] & U[2j+9] & C[2j+1]
@@ -135,28 +192,25 @@ sora_ahead(uint32_t x, uint32_t xn, int k) {
  */
 SORA_HD void
 sora_lane_predicate(uint32_t nue, uint32_t nuo, uint32_t de, uint32_t dod,
-	uint32_t ce, uint32_t co,
-	uint32_t nue_n, uint32_t nuo_n, uint32_t de_n, uint32_t dod_n,
-	uint32_t *pred_e, uint32_t *pred_o) {
-    *pred_e = de & ~nuo & sora_ahead(de, de_n, 1) & sora_ahead(dod, dod_n, 3) &
-	    ~sora_ahead(nue, nue_n, 4) & ce;
-    *pred_o = dod & ~sora_ahead(nue, nue_n, 1) & sora_ahead(dod, dod_n, 1) &
-	    sora_ahead(de, de_n, 4) & ~sora_ahead(nuo, nuo_n, 4) & co;
+	uint32_t ce, uint32_t co, uint32_t *pred_e, uint32_t *pred_o) {
+    *pred_e = de & ~nuo & (de << 1) & (dod << 3) & ~(nue << 4) & ce & 0xffff0000u;
+    *pred_o = dod & ~(nue << 1) & (dod << 1) & (de << 4) & ~(nuo << 4) & co &
+	    0xffff0000u;
 }
 
-/* mask with the first `count` elements set (MSB first), count clamped to [0,32] */
+/* mask with the first `count` elements set (MSB first), count clamped to [0,16] */
 SORA_HD uint32_t
 sora_first_elements(int64_t count) {
     if (count <= 0)
 	return 0;
-    if (count >= 32)
-	return 0xffffffffu;
+    if (count >= 16)
+	return 0xffff0000u;
     return 0xffffffffu << (32 - (int) count);
 }
 
 /*
- * Owned-position masks of lane g: tile-local positions 64g+2b (even) and
- * 64g+2b+1 (odd) are kept iff below `limit` (the number of positions of this
+ * Owned-position masks of lane g: tile-local positions 32g+2b (even) and
+ * 32g+2b+1 (odd) are kept iff below `limit` (the number of positions of this
  * tile that are to be scanned) and the lane is not a halo lane.
  */
 SORA_HD void
@@ -171,11 +225,32 @@ sora_lane_valid(int g, int64_t limit, uint32_t *valid_e, uint32_t *valid_o) {
 
 /* ---- a7..a9: one candidate out of the NU bit arrays ---- */
 
-/* CRC-24 byte table, generator 0x1FFF409 (plane.c:373-385), MSB first */
-SORA_HD uint32_t
+/* CRC-24, generator 0x1FFF409 (plane.c:373-385), MSB first: byte * x^24 mod G */
+SORA_HD constexpr uint32_t
 sora_crc24_table_entry(uint32_t byte) {
     uint32_t r = byte << 16;
     for (int i = 0; i < 8; i++) {
+	r <<= 1;
+	if (r & 0x1000000u)
+	    r ^= 0x1fff409u;
+    }
+    return r & 0xffffffu;
+}
+
+/*
+ * Sliced tables: the CRC over the first 88 bits (11 bytes b0..b10) of a
+ * message is the XOR over k of T[k][b_k], T[k][v] = v * x^(8*(10-k)+24) mod G
+ * (the CRC is linear and starts from 0).  The CRC over the first 32 bits is
+ * the XOR of T[7+k][b_k], k = 0..3.  Eleven independent lookups instead of a
+ * chain of eleven dependent ones.
+ */
+#define SORA_CRC_SLICES		11
+#define SORA_CRC_TABLE_WORDS	(SORA_CRC_SLICES * 256)
+
+SORA_HD constexpr uint32_t
+sora_crc24_slice_entry(int k, uint32_t byte) {
+    uint32_t r = sora_crc24_table_entry(byte);
+    for (int i = 0; i < 8 * (10 - k); i++) {
 	r <<= 1;
 	if (r & 0x1000000u)
 	    r ^= 0x1fff409u;
@@ -210,29 +285,30 @@ sora_extract_bits(const uint32_t *words, uint32_t e, uint32_t bits[4]) {
     bits[3] &= 0xffff0000u;
 }
 
-/* plane.c:461-484 up to, but excluding, the plane-set lookup */
+/* plane.c:461-484 up to, but excluding, the plane-set lookup.
+ * tables: SORA_CRC_TABLE_WORDS sliced CRC words (sora_crc24_slice_entry) */
 SORA_HD void
-sora_classify(const uint32_t bits[4], const uint32_t *crc_table,
+sora_classify(const uint32_t bits[4], const uint32_t *tables,
 	struct sora_candidate *c) {
-    uint32_t df = bits[0] >> 27;
-    uint32_t is_long = df >= 16 && df <= 24;		/* plane.c:462 */
-    uint32_t crc = 0, ap;
+    const uint32_t df = bits[0] >> 27;
+    const uint32_t is_long = df >= 16 && df <= 24;	/* plane.c:462 */
+    const uint32_t lmask = is_long? 0xffffffffu : 0u;
+    /* bytes 0..3 use slices 0..3 when long, 7..10 when short */
+    const uint32_t *t03 = tables + (is_long? 0 : 7 * 256);
+    uint32_t crc, ap;
 
     /* plane.c:472: CRC over the first 32 bits, or 88 when long */
-    for (int i = 3; i >= 0; i--)
-	crc = ((crc << 8) ^ crc_table[((crc >> 16) ^ (bits[0] >> (8 * i))) & 0xff])
-		& 0xffffffu;
-    if (is_long) {
-	for (int i = 3; i >= 0; i--)
-	    crc = ((crc << 8) ^
-		    crc_table[((crc >> 16) ^ (bits[1] >> (8 * i))) & 0xff]) & 0xffffffu;
-	for (int i = 3; i >= 1; i--)
-	    crc = ((crc << 8) ^
-		    crc_table[((crc >> 16) ^ (bits[2] >> (8 * i))) & 0xff]) & 0xffffffu;
-	ap = ((bits[2] & 0xffu) << 16) | (bits[3] >> 16);	/* bits[88,112) */
-    } else {
-	ap = bits[1] >> 8;					/* bits[32,56) */
-    }
+    crc = t03[bits[0] >> 24] ^ t03[256 + ((bits[0] >> 16) & 0xff)] ^
+	    t03[512 + ((bits[0] >> 8) & 0xff)] ^ t03[768 + (bits[0] & 0xff)];
+    crc ^= (tables[4 * 256 + (bits[1] >> 24)] ^
+	    tables[5 * 256 + ((bits[1] >> 16) & 0xff)] ^
+	    tables[6 * 256 + ((bits[1] >> 8) & 0xff)] ^
+	    tables[7 * 256 + (bits[1] & 0xff)] ^
+	    tables[8 * 256 + (bits[2] >> 24)] ^
+	    tables[9 * 256 + ((bits[2] >> 16) & 0xff)] ^
+	    tables[10 * 256 + ((bits[2] >> 8) & 0xff)]) & lmask;
+    ap = is_long? (((bits[2] & 0xffu) << 16) | (bits[3] >> 16))	/* bits[88,112) */
+	    : (bits[1] >> 8);					/* bits[32,56) */
 
     c->bits[0] = bits[0]; c->bits[1] = bits[1];
     c->bits[2] = bits[2]; c->bits[3] = bits[3];

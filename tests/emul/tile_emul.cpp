@@ -20,19 +20,23 @@ emul_scan8(const uint8_t *iq, uint64_t n_samples, uint64_t n_scan, int encoding,
     const uint32_t flip = encoding == 1? 0x80808080u : 0u;
     const uint64_t n_tiles = (n_scan + SORA_TILE_POS - 1) / SORA_TILE_POS;
     std::vector<uint32_t> s_m(SORA_M_DWORDS);
-    std::vector<uint32_t> s_nue(SORA_WORDS), s_nuo(SORA_WORDS), s_de(SORA_WORDS),
-	    s_do(SORA_WORDS), w_ce(SORA_WORDS), w_co(SORA_WORDS);
-    uint32_t crc_table[256];
+    /* 16-bit halves, one per lane, read back as 32-bit words (little endian) */
+    std::vector<uint16_t> s_nue(2 * SORA_WORDS), s_nuo(2 * SORA_WORDS),
+	    s_de(2 * SORA_WORDS), s_do(2 * SORA_WORDS);
+    std::vector<uint32_t> l_c(SORA_TILE_THREADS);
+    std::vector<uint32_t> crc_table(SORA_CRC_TABLE_WORDS);
     size_t n_out = 0;
+    const int loads = SORA_TILE_SAMPLES * 2 / 16 / SORA_TILE_THREADS;
 
-    for (uint32_t i = 0; i < 256; i++)
-	crc_table[i] = sora_crc24_table_entry(i);
+    for (int k = 0; k < SORA_CRC_SLICES; k++)
+	for (uint32_t i = 0; i < 256; i++)
+	    crc_table[k * 256 + i] = sora_crc24_slice_entry(k, i);
 
     for (uint64_t tile = 0; tile < n_tiles; tile++) {
 	const uint64_t tile_start = tile * SORA_TILE_POS;
 
 	/* phase 1 */
-	for (int r = 0; r < 8; r++)
+	for (int r = 0; r < loads; r++)
 	    for (uint32_t tid = 0; tid < SORA_TILE_THREADS; tid++) {
 		uint32_t pair = (r * SORA_TILE_THREADS + tid) * 4;
 		for (int k = 0; k < 4; k++) {
@@ -47,7 +51,7 @@ emul_scan8(const uint8_t *iq, uint64_t n_samples, uint64_t n_scan, int encoding,
 				b[c] = iq[byte + c];
 			v = b[0] | (b[1] << 8) | (b[2] << 16) | ((uint32_t) b[3] << 24);
 		    }
-		    s_m[pair + k + 4 * ((pair + k) >> 5)] = sora_mag2_pack8(v, flip);
+		    s_m[pair + 4 * (pair >> 4) + k] = sora_mag2_pack8(v, flip);
 		}
 	    }
 	for (int k = 0; k < 4; k++)
@@ -55,16 +59,22 @@ emul_scan8(const uint8_t *iq, uint64_t n_samples, uint64_t n_scan, int encoding,
 
 	/* phase 2 */
 	for (uint32_t tid = 0; tid < SORA_TILE_THREADS; tid++) {
-	    uint32_t P[SORA_LANE_STRIDE];
-	    for (int i = 0; i < 32; i++)
+	    uint32_t P[SORA_LANE_STRIDE], up, down, cc;
+	    for (int i = 0; i < SORA_LANE_PAIRS; i++)
 		P[i] = s_m[tid * SORA_LANE_STRIDE + i];
 	    for (int i = 0; i < 4; i++)
-		P[32 + i] = s_m[(tid + 1) * SORA_LANE_STRIDE + i];
-	    sora_lane_compare(P, &s_nue[tid], &s_nuo[tid], &s_de[tid], &s_do[tid],
-		    &w_ce[tid], &w_co[tid]);
+		P[SORA_LANE_PAIRS + i] = s_m[(tid + 1) * SORA_LANE_STRIDE + i];
+	    sora_lane_compare(P, &up, &down, &cc);
+	    s_nue[tid ^ 1] = (uint16_t) (~up & 0xffffu);
+	    s_nuo[tid ^ 1] = (uint16_t) ((~up) >> 16);
+	    s_de[tid ^ 1] = (uint16_t) (down & 0xffffu);
+	    s_do[tid ^ 1] = (uint16_t) (down >> 16);
+	    l_c[tid] = cc;
 	}
-	s_nue[SORA_TILE_THREADS] = s_nuo[SORA_TILE_THREADS] = 0;
-	s_de[SORA_TILE_THREADS] = s_do[SORA_TILE_THREADS] = 0;
+	for (int k = 0; k < 2; k++) {
+	    s_nue[SORA_TILE_THREADS + k] = s_nuo[SORA_TILE_THREADS + k] = 0;
+	    s_de[SORA_TILE_THREADS + k] = s_do[SORA_TILE_THREADS + k] = 0;
+	}
 
 	/* phase 3 */
 	std::vector<uint16_t> queue;
@@ -73,9 +83,12 @@ emul_scan8(const uint8_t *iq, uint64_t n_samples, uint64_t n_scan, int encoding,
 		: (int64_t) SORA_TILE_POS;
 	for (uint32_t tid = 0; tid < SORA_TILE_THREADS; tid++) {
 	    uint32_t pe, po, ve, vo;
-	    sora_lane_predicate(s_nue[tid], s_nuo[tid], s_de[tid], s_do[tid],
-		    w_ce[tid], w_co[tid], s_nue[tid + 1], s_nuo[tid + 1],
-		    s_de[tid + 1], s_do[tid + 1], &pe, &po);
+	    const uint32_t me = tid ^ 1, nx = (tid + 1) ^ 1;
+	    sora_lane_predicate(((uint32_t) s_nue[me] << 16) | s_nue[nx],
+		    ((uint32_t) s_nuo[me] << 16) | s_nuo[nx],
+		    ((uint32_t) s_de[me] << 16) | s_de[nx],
+		    ((uint32_t) s_do[me] << 16) | s_do[nx],
+		    l_c[tid] << 16, l_c[tid] & 0xffff0000u, &pe, &po);
 	    sora_lane_valid((int) tid, limit, &ve, &vo);
 	    pe &= ve;
 	    po &= vo;
@@ -96,12 +109,13 @@ emul_scan8(const uint8_t *iq, uint64_t n_samples, uint64_t n_scan, int encoding,
 	/* phase 4 */
 	for (size_t i = 0; i < queue.size(); i++) {
 	    uint32_t q = queue[i];
-	    const uint32_t *words = (q & 1)? s_nuo.data() : s_nue.data();
+	    const uint32_t *words = reinterpret_cast<const uint32_t *>(
+		    (q & 1)? s_nuo.data() : s_nue.data());
 	    uint32_t bits[4];
 	    sora_candidate c;
 
 	    sora_extract_bits(words, (q >> 1) + 8, bits);
-	    sora_classify(bits, crc_table, &c);
+	    sora_classify(bits, crc_table.data(), &c);
 	    uint64_t kind = !c.squitter? SORA_REC_KIND_REPLY :
 		    c.syndrome == 0? SORA_REC_KIND_SQUITTER : SORA_REC_KIND_DIRTY;
 	    if (kind == SORA_REC_KIND_DIRTY && !emit_all)
