@@ -11,7 +11,8 @@
  * cannot be built (it needs GTK2/FFTW3), so this file
  * restates only its ADS-B branch.
  *
- * usage: ref_sora_adsb [--adsb-to-bitstring] < capture.uc8
+ * usage: ref_sora_adsb [--adsb-from-raw] [--adsb-to-bitstring] < capture.uc8
+ *        (without --adsb-from-raw the input is the ASCII bit-string format)
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -22,16 +23,16 @@
 
 int
 main(int argc, char *argv[]) {
-    int flags = PLANES_INPUT_FROM_RAW;
+    int flags = 0;
     int to_bitstring = 0;
     int i;
 
     for (i = 1; i < argc; i++) {
 	if (strcmp(argv[i], "--adsb-to-bitstring") == 0)
 	    to_bitstring = 1;
-	else if (strcmp(argv[i], "--adsb-decode") == 0 ||
-		strcmp(argv[i], "--adsb-from-raw") == 0 ||
-		strcmp(argv[i], "-d") == 0)
+	else if (strcmp(argv[i], "--adsb-from-raw") == 0)
+	    flags |= PLANES_INPUT_FROM_RAW;
+	else if (strcmp(argv[i], "--adsb-decode") == 0 || strcmp(argv[i], "-d") == 0)
 	    ;
 	else {
 	    fprintf(stderr, "unknown argument %s\n", argv[i]);

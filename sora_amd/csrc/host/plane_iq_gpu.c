@@ -1,0 +1,218 @@
+/*
+ * plane_iq_gpu.c -- the demodulator iterator of reference
+ * src/ads-b/plane-iq.h:10-13 on top of the gfx950 library.
+ *
+ * The reference pulls one sample at a time through a 4096-float ring
+ * (plane-iq.c:141-194).  Here the stream is read in blocks of tens of
+ * millions of samples, every block is handed to the device together with the
+ * last 239 samples of the previous one (a candidate at p reads p .. p+239),
+ * and the frames the device returns are yielded one per call, in position
+ * order -- the order in which the reference completes them (plane-iq.c:76-83).
+ *
+ * Time: the reference stamps a candidate with gettimeofday() when it meets
+ * the preamble (plane-iq.c:46), i.e. with the time at which it happened to
+ * process that sample.  Here the stamp is stream time,
+ *     t = T0 + position / RATE,
+ * T0 = gettimeofday() when the state is created unless SORA_T0 is set,
+ * RATE = SORA_RATE or 2 MS/s: the same for every run over the same capture.
+ */
+#include <stdlib.h>
+#include <string.h>
+
+#include "sora_adsb_gpu.h"
+#include "sora_adsb_host.h"
+
+#define DEFAULT_BLOCK_SAMPLES	(32u << 20)	/* 64 MB of uc8 per submit */
+
+struct plane_iq_state {
+    FILE *f;
+    int encoding;
+    int bytes_per_sample;
+    sora_adsb_ctx *ctx;
+
+    unsigned char *buf;		/* tail of the previous block + this block */
+    size_t block_samples;
+    size_t tail_samples;	/* samples carried over, <= 239 */
+    unsigned long long next_position;	/* stream index of buf[0] */
+    int eof;
+
+    struct sora_adsb_frame *frames;
+    size_t frames_cap, n_frames, next_frame;
+
+    long long t0;
+    unsigned long long rate;
+    unsigned long long last_position;
+    int error;
+    char msg[SORA_ADSB_MSG_BITS + 1];
+};
+
+static int
+encoding_bytes(int encoding) {
+    switch (encoding) {
+    case SORA_ENC_UC8:
+    case SORA_ENC_SC8:
+	return 2;
+    case SORA_ENC_SC16:
+	return 4;
+    default:
+	return 0;
+    }
+}
+
+struct plane_iq_state *
+plane_iq_state_new_encoded(FILE *f, int encoding) {
+    struct plane_iq_state *st;
+    struct sora_adsb_config cfg;
+    const char *s;
+    int rc;
+
+    if (encoding_bytes(encoding) == 0) {
+	fprintf(stderr, "sora: unsupported encoding %d for ADS-B input\n", encoding);
+	return NULL;
+    }
+    st = calloc(1, sizeof *st);
+    if (st == NULL)
+	return NULL;
+    st->f = f;
+    st->encoding = encoding;
+    st->bytes_per_sample = encoding_bytes(encoding);
+    st->block_samples = DEFAULT_BLOCK_SAMPLES;
+    if ((s = getenv("SORA_ADSB_BLOCK_SAMPLES")) != NULL && atoll(s) >= 1024)
+	st->block_samples = (size_t) atoll(s);
+
+    if ((s = getenv("SORA_T0")) != NULL)
+	st->t0 = atoll(s);
+    else {
+	struct timeval now;
+	(void) gettimeofday(&now, NULL);
+	st->t0 = now.tv_sec;
+    }
+    st->rate = 2000000ull;
+    if ((s = getenv("SORA_RATE")) != NULL && strtoull(s, NULL, 10) > 0)
+	st->rate = strtoull(s, NULL, 10);
+
+    memset(&cfg, 0, sizeof cfg);
+    cfg.max_chunk_samples = st->block_samples + SORA_ADSB_HALO;
+    cfg.emit_mode = SORA_EMIT_ACCEPTED;
+    if ((s = getenv("SORA_ADSB_EMIT_ALL")) != NULL && atoi(s) != 0) {
+	cfg.emit_mode = SORA_EMIT_CANDIDATES;
+	cfg.max_candidates = cfg.max_chunk_samples / 2 + 1024;
+    }
+    /* a block cannot hold more accepted frames than one per 2 positions */
+    cfg.max_squitters = cfg.max_chunk_samples / 64 + 65536;
+    s = getenv("SORA_ADSB_DEVICE");
+    rc = sora_adsb_create(&st->ctx, s != NULL? atoi(s) : 0, &cfg);
+    if (rc != SORA_OK) {
+	fprintf(stderr, "sora: cannot use the GPU ADS-B path: %s (%s)\n",
+		sora_adsb_strerror(rc), sora_adsb_last_error(st->ctx));
+	sora_adsb_destroy(st->ctx);
+	free(st);
+	return NULL;
+    }
+
+    st->buf = malloc((st->block_samples + SORA_ADSB_HALO) * (size_t) st->bytes_per_sample);
+    st->frames_cap = cfg.emit_mode == SORA_EMIT_CANDIDATES?
+	    (size_t) cfg.max_candidates : (size_t) cfg.max_squitters;
+    st->frames = malloc(st->frames_cap * sizeof *st->frames);
+    if (st->buf == NULL || st->frames == NULL) {
+	fprintf(stderr, "sora: out of memory\n");
+	plane_iq_state_delete(st);
+	return NULL;
+    }
+    return st;
+}
+
+struct plane_iq_state *
+plane_iq_state_new(FILE *f) {
+    return plane_iq_state_new_encoded(f, SORA_ENC_UC8);	/* plane-iq.c:121-139 */
+}
+
+void
+plane_iq_state_delete(struct plane_iq_state *st) {
+    if (st == NULL)
+	return;
+    sora_adsb_destroy(st->ctx);
+    free(st->buf);
+    free(st->frames);
+    free(st);			/* the FILE stays open, like plane-iq.c:114-119 */
+}
+
+/* reads the next block, runs it on the device; 0 when the stream is over */
+static int
+next_block(struct plane_iq_state *st) {
+    const size_t bps = (size_t) st->bytes_per_sample;
+    size_t got, n_samples, n_owned;
+    int rc;
+
+    if (st->eof)
+	return 0;
+    /* whole samples only; a trailing partial sample is dropped
+     * (plane-iq.c:131, :138; radio-file.c:122) */
+    got = fread(st->buf + st->tail_samples * bps, bps, st->block_samples, st->f);
+    if (got < st->block_samples)
+	st->eof = 1;
+    n_samples = st->tail_samples + got;
+    /* every position whose 240-sample window is complete; at the end of the
+     * stream the device drops p + 240 > n itself (plane-iq.c:148-166) */
+    n_owned = st->eof? n_samples :
+	    (n_samples >= SORA_ADSB_HALO? n_samples - SORA_ADSB_HALO : 0);
+
+    rc = sora_adsb_submit_host(st->ctx, st->buf, n_samples * bps, st->encoding,
+	    st->next_position, n_owned);
+    if (rc == SORA_OK)
+	rc = sora_adsb_collect(st->ctx, st->frames, st->frames_cap, &st->n_frames);
+    if (rc != SORA_OK) {
+	fprintf(stderr, "sora: GPU ADS-B path failed: %s (%s)\n",
+		sora_adsb_strerror(rc), sora_adsb_last_error(st->ctx));
+	st->error = rc;
+	st->eof = 1;
+	st->n_frames = 0;
+	return 0;
+    }
+    if (st->n_frames > st->frames_cap)
+	st->n_frames = st->frames_cap;
+    st->next_frame = 0;
+
+    if (!st->eof) {
+	/* carry the unowned tail */
+	const size_t keep = n_samples - n_owned;
+	memmove(st->buf, st->buf + n_owned * bps, keep * bps);
+	st->tail_samples = keep;
+	st->next_position += n_owned;
+    }
+    return 1;
+}
+
+const char *
+plane_iq_get_next(struct plane_iq_state *st, struct timeval *tvp, double *amplitude) {
+    const struct sora_adsb_frame *fr;
+    int k;
+
+    if (st == NULL)
+	return NULL;
+    while (st->next_frame >= st->n_frames) {
+	st->n_frames = st->next_frame = 0;
+	if (!next_block(st))
+	    return NULL;
+    }
+    fr = &st->frames[st->next_frame++];
+
+    for (k = 0; k < SORA_ADSB_MSG_BITS; k++)
+	st->msg[k] = (char) ('0' + ((fr->bits[k >> 5] >> (31 - (k & 31))) & 1u));
+    st->msg[SORA_ADSB_MSG_BITS] = '\0';
+    st->last_position = fr->position;
+    tvp->tv_sec = (time_t) (st->t0 + (long long) (fr->position / st->rate));
+    tvp->tv_usec = (suseconds_t) ((fr->position % st->rate) * 1000000ull / st->rate);
+    *amplitude = fr->amplitude_56 / 56;		/* plane-iq.c:189 */
+    return st->msg;
+}
+
+unsigned long long
+plane_iq_last_position(const struct plane_iq_state *st) {
+    return st->last_position;
+}
+
+int
+plane_iq_error(const struct plane_iq_state *st) {
+    return st != NULL? st->error : SORA_ERR_INVALID;
+}

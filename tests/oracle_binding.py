@@ -170,10 +170,11 @@ def ref_candidates(iq_bytes, optimized=True, accepted_only=False):
     return out, final
 
 
-def ref_main_loop(iq_bytes, bitstring=False, shim=True, env=None):
-    """stdout of the compiled reference chain (`sora --adsb-decode --adsb-from-raw`)."""
+def ref_main_loop(iq_bytes, bitstring=False, shim=True, env=None, from_raw=True):
+    """stdout of the compiled reference chain (`sora --adsb-decode --adsb-from-raw`;
+    from_raw=False: the ASCII bit-string input mode)."""
     exe = os.path.join(REF_DIR, "ref_sora_adsb_shim" if shim else "ref_sora_adsb")
-    args = [exe, "--adsb-decode", "--adsb-from-raw"]
+    args = [exe, "--adsb-decode"] + (["--adsb-from-raw"] if from_raw else [])
     if bitstring:
         args.append("--adsb-to-bitstring")
     e = dict(os.environ)

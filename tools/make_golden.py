@@ -91,6 +91,12 @@ def main():
             fh.write(ob.ref_main_loop(raw, bitstring=False, shim=True, env=env))
         with open(os.path.join(GOLDEN, name + ".bitstring.txt"), "w") as fh:
             fh.write(ob.ref_main_loop(raw, bitstring=True, shim=True, env=env))
+        # the ASCII input mode (planes-main-loop.c:15-47) fed with that bit-string text
+        with open(os.path.join(GOLDEN, name + ".bitstring.txt"), "rb") as fh:
+            ascii_in = fh.read()
+        with open(os.path.join(GOLDEN, name + ".decoded_from_ascii.txt"), "w") as fh:
+            fh.write(ob.ref_main_loop(ascii_in, bitstring=False, shim=False, env=env,
+                                      from_raw=False))
         index[name] = dict(nbytes=len(raw), candidates=len(cands),
                            accepted=sum(c["accepted"] for c in cands),
                            final_position=final)
