@@ -88,6 +88,7 @@ def main():
 
     import sora_amd
     from sora_amd import ENC_UC8, FRAME_DTYPE, AdsbContext, synth
+    from sora_amd.sharded import ShardedDecoder
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -124,58 +125,26 @@ def main():
     max_frames = per_gpu // 1024 + 65536        # ~3x the injected frame rate
     ctx = AdsbContext(n_local, device=local, max_squitters=max_frames,
                       max_frames=max_frames)
-    fsz = FRAME_DTYPE.itemsize
     collective = world > 1 or args.force_collective
-    n_host = max_frames * (world if rank == 0 else 1)
-    h_pin = torch.empty(n_host * fsz, dtype=torch.uint8, pin_memory=True)
-    h_frames = h_pin.numpy().view(FRAME_DTYPE)
     if collective:
-        d_sq = torch.zeros(max_frames, dtype=torch.int64, device=dev)
-        d_sq_all = torch.zeros(world * max_frames, dtype=torch.int64, device=dev)
-        d_out = torch.zeros(max_frames * fsz, dtype=torch.uint8, device=dev)
-        d_gather = ([torch.zeros_like(d_out) for _ in range(world)] if rank == 0 else None)
-        counts_all = torch.zeros(world, dtype=torch.int64, device=dev)
+        # scan -> squitter-record all-gather -> resolve -> frame-list gather
+        sharded = ShardedDecoder(ctx, rank, world, dev, max_frames)
+        h_frames = sharded.h_frames
+    else:
+        h_pin = torch.empty(max_frames * FRAME_DTYPE.itemsize, dtype=torch.uint8,
+                            pin_memory=True)
+        h_frames = h_pin.numpy().view(FRAME_DTYPE)
 
     scan_ms = []
 
-    def all_counts(k):
-        dist.all_gather_into_tensor(counts_all,
-                                    torch.tensor([k], dtype=torch.int64, device=dev))
-        return [int(x) for x in counts_all.tolist()]
-
     def step():
-        ctx.reset()                                          # a new capture: no known planes
-        ctx.scan(d_iq, 2 * n_local, ENC_UC8, base_position=first, n_owned=per_gpu)
         if collective:
-            # the one exchange of the path: clean squitter
-            # records (position << 24 | address, 8 bytes each), all-gathered
-            ks = all_counts(ctx.squitter_count())
-            m = max(ks)
-            if m:
-                ctx.copy_squitters(d_sq, max_frames)
-                ctx.synchronize()
-                dist.all_gather_into_tensor(d_sq_all[:world * m], d_sq[:m])
-                for r in range(world):
-                    if r != rank and ks[r]:
-                        ctx.add_known(d_sq_all[r * m:], ks[r])
-        ctx.resolve()
-        if not collective:
-            n = ctx.collect_into(h_frames)                   # frame list in host memory
+            n = sharded.step(d_iq, 2 * n_local, ENC_UC8, first, per_gpu)
         else:
-            # only the compacted frame lists cross xGMI, gathered to rank 0
-            ns = all_counts(ctx.collect_device(d_out, max_frames))
-            m = max(ns) * fsz
-            if m:
-                dist.gather(d_out[:m], [g[:m] for g in d_gather] if rank == 0 else None,
-                            dst=0)
-            n = sum(ns)
-            if rank == 0:
-                off = 0
-                for r in range(world):
-                    nb = ns[r] * fsz
-                    h_pin[off:off + nb].copy_(d_gather[r][:nb], non_blocking=True)
-                    off += nb
-                torch.cuda.synchronize()
+            ctx.reset()                                      # a new capture: no known planes
+            ctx.submit_device(d_iq, 2 * n_local, ENC_UC8, base_position=first,
+                              n_owned=per_gpu)
+            n = ctx.collect_into(h_frames)                   # frame list in host memory
         scan_ms.append(ctx.last_scan_ms())
         return n
 

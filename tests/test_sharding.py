@@ -1,0 +1,126 @@
+"""CPU tier: the N>1 path (sora_amd/sharded.py) with world_size 2 over gloo.
+
+The per-rank device context is replaced by an oracle-backed stand-in with the
+same interface (tests may use the oracle; the product never does), so what is
+tested is what sharded.py owns: the shard plan and its halos, the squitter
+record exchange, the first-seen rule across shards, and the rank-ordered gather.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle_binding as ob
+from sora_amd import FRAME_ACCEPTED, FRAME_DTYPE, FRAME_SQUITTER, string_to_bits, synth
+from sora_amd.sharded import ShardedDecoder, plan_shards
+
+
+class OracleContext:
+    """AdsbContext's interface on CPU tensors, computed by the oracle."""
+
+    def __init__(self):
+        self.known = {}                 # address -> first global position
+
+    def reset(self):
+        self.known = {}
+
+    def scan(self, d_iq, nbytes, encoding, base_position=0, n_owned=None):
+        raw = d_iq[:nbytes].numpy().tobytes()
+        # every candidate, judged later against first-seen positions
+        self.cands = [c for c in ob.scan(raw, encoding, base_position=base_position)
+                      if c["position"] < base_position + n_owned]
+        self.squitters = [c for c in self.cands
+                          if c["df"] in (11, 17, 18) and c["syndrome"] == 0]
+
+    def squitter_count(self):
+        return len(self.squitters)
+
+    def copy_squitters(self, d_dst, cap):
+        rec = [(c["position"] << 24) | c["address"] for c in self.squitters][:cap]
+        d_dst[:len(rec)] = torch.tensor(rec, dtype=torch.int64)
+
+    def synchronize(self):
+        pass
+
+    def _note(self, address, position):
+        if position < self.known.get(address, 1 << 62):
+            self.known[address] = position
+
+    def add_known(self, d_records, n):
+        for r in d_records[:n].tolist():
+            self._note(r & 0xFFFFFF, r >> 24)
+
+    def resolve(self):
+        for c in self.squitters:
+            self._note(c["address"], c["position"])
+        out = []
+        for c in self.cands:
+            squitter = c["df"] in (11, 17, 18)
+            ok = (c["syndrome"] == 0) if squitter else \
+                self.known.get(c["address"], 1 << 62) < c["position"]
+            if ok:
+                out.append((c, squitter))
+        self.frames = np.zeros(len(out), dtype=FRAME_DTYPE)
+        for i, (c, squitter) in enumerate(out):
+            self.frames[i] = (c["position"], tuple(string_to_bits(c["bits"])),
+                              c["amplitude_56"], c["syndrome"], c["address"], 0, c["df"],
+                              -1, FRAME_ACCEPTED | (FRAME_SQUITTER if squitter else 0), 0)
+
+    def collect_device(self, d_out, cap):
+        raw = torch.from_numpy(self.frames.view(np.uint8).copy())
+        d_out[:raw.numel()] = raw
+        return len(self.frames)
+
+
+def _worker(rank, world, port, raw, result_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        total = len(raw) // 2
+        first, owned, local = plan_shards(total, world)[rank]
+        shard = torch.frombuffer(bytearray(raw[2 * first:2 * (first + local)]),
+                                 dtype=torch.uint8)
+        dec = ShardedDecoder(OracleContext(), rank, world, torch.device("cpu"), 20000)
+        for _ in range(2):                      # twice: reset between captures works
+            n = dec.step(shard, 2 * local, ob.ENC_UC8, first, owned)
+        if rank == 0:
+            np.save(result_path, dec.h_frames[:n].copy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_plan_shards():
+    plan = plan_shards(1000003, 4)
+    assert sum(p[1] for p in plan) == 1000003
+    assert all(p[0] % 8 == 0 for p in plan)
+    assert [p[2] - p[1] for p in plan] == [239, 239, 239, 0]
+    assert plan_shards(100, 8)[-1] == (100, 0, 0)       # more ranks than work
+
+
+@pytest.mark.timeout(300)
+def test_two_ranks_equal_one(tmp_path):
+    p = synth.default_params(2, n_samples=300000, mean_gap=900, reply_permille=300,
+                             unknown_permille=250, n_icao=5, seed=21)
+    raw = synth.fill_host(p.n_samples, p.encoding, p.seed, synth.make_frames(p)).tobytes()
+    want = [c for c in ob.scan(raw) if c["accepted"]]
+    # the stateful rule must cross the shard boundary in this capture
+    half = plan_shards(p.n_samples, 2)[1][0]
+    late = [c for c in want if c["position"] >= half and c["df"] not in (11, 17, 18)]
+    assert late, "test capture has no reply in the second shard"
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "frames.npy")
+    mp.spawn(_worker, args=(2, port, raw, out), nprocs=2, join=True)
+    got = np.load(out)
+    assert [int(f["position"]) for f in got] == [c["position"] for c in want]
+    from sora_amd import bits_to_string
+    assert [bits_to_string(f["bits"]) for f in got] == [c["bits"] for c in want]
+    assert [float(f["amplitude_56"]) for f in got] == [c["amplitude_56"] for c in want]
