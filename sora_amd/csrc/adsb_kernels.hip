@@ -69,15 +69,35 @@ rank_in_mask(unsigned long long mask) {
 	    __builtin_amdgcn_mbcnt_lo((uint32_t) mask, 0));
 }
 
-/* inclusive prefix sum over the 64 lanes of a wave, six DPP adds */
+/* inclusive prefix sum over the 64 lanes of a wave: six v_add_u32_dpp
+ * (row_shr 1/2/4/8 within rows of 16, then row_bcast 15 and 31); lanes a DPP
+ * source does not reach read 0 (bound_ctrl) or keep their value (row_mask).
+ * The two s_nop cover the VALU-write -> DPP-read hazard of gfx9. */
 __device__ __forceinline__ uint32_t
 wave_inclusive_scan(uint32_t v) {
-    v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x111, 0xf, 0xf, false);
-    v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x112, 0xf, 0xf, false);
-    v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x114, 0xf, 0xf, false);
-    v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x118, 0xf, 0xf, false);
-    v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x142, 0xa, 0xf, false);
-    v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x143, 0xc, 0xf, false);
+#ifdef SORA_NO_ASM_SCAN
+    const uint32_t lane = threadIdx.x & 63;
+    for (int d = 1; d < 64; d <<= 1) {
+	uint32_t o = __shfl_up(v, d, 64);
+	if (lane >= (uint32_t) d)
+	    v += o;
+    }
+    return v;
+#endif
+    asm("s_nop 1\n\t"
+	"v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+	"s_nop 1\n\t"
+	"v_add_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+	"s_nop 1\n\t"
+	"v_add_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+	"s_nop 1\n\t"
+	"v_add_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+	"s_nop 1\n\t"
+	"v_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+	"s_nop 1\n\t"
+	"v_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+	"s_nop 1"
+	: "+v"(v));
     return v;
 }
 

@@ -75,6 +75,8 @@ sora_mag2_pack8(uint32_t iq, uint32_t flip) {
      * (b - 128, plane-iq.c:132-133); 0 for sc8 */
     uint32_t x = iq ^ flip;
 #if defined(__HIP_DEVICE_COMPILE__)
+    /* the builtin, not inline asm of the VOP3P form with an inline-0
+     * accumulator: that variant returned wrong sums on gfx950 hardware */
     int lo = (int) (x & 0xffffu), hi = (int) (x >> 16);
     uint32_t m0 = (uint32_t) __builtin_amdgcn_sdot4(lo, lo, 0, false);
     uint32_t m1 = (uint32_t) __builtin_amdgcn_sdot4(hi, hi, 0, false);
