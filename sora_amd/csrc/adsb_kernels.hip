@@ -150,7 +150,7 @@ adsb_scan8_kernel(sora_scan_args a) {
     uint64_t *rec_out = a.rec + (uint64_t) group * a.rec_cap;
     uint64_t *sq_out = a.sq + (uint64_t) group * a.sq_cap;
     uint32_t n_rec = 0, n_sq = 0;		/* workgroup-uniform */
-    uint32_t st_cand = 0, st_sq = 0, st_dirty = 0, st_reply = 0;
+    uint32_t st_cand = 0, st_sq = 0, st_dirty = 0;
 
     uint16_t *s_queue = reinterpret_cast<uint16_t *>(s_m);
     uint32_t *s_crc = s_m + kCrcTableDword;
@@ -182,11 +182,10 @@ adsb_scan8_kernel(sora_scan_args a) {
 #pragma unroll
 	    for (int r = 0; r < kLoads; r++) {
 		uint32_t pair = (r * kThreads + tid) * 4;
-		u32x4 m;
-		m[0] = sora_mag2_pack8(v[r][0], flip);
-		m[1] = sora_mag2_pack8(v[r][1], flip);
-		m[2] = sora_mag2_pack8(v[r][2], flip);
-		m[3] = sora_mag2_pack8(v[r][3], flip);
+		const uint32_t raw[4] = {v[r][0], v[r][1], v[r][2], v[r][3]};
+		uint32_t mm[4];
+		sora_mag2_pack8x4(raw, flip, mm);
+		const u32x4 m = {mm[0], mm[1], mm[2], mm[3]};
 		*reinterpret_cast<u32x4 *>(&s_m[pair + 4 * (pair >> 4)]) = m;
 	    }
 	    if (tid < 4)
@@ -323,9 +322,9 @@ adsb_scan8_kernel(sora_scan_args a) {
 		    if (k < a.sq_cap)
 			sq_out[k] = record;
 		}
-		st_sq += kind == SORA_REC_KIND_SQUITTER;
-		st_dirty += kind == SORA_REC_KIND_DIRTY;
-		st_reply += kind == SORA_REC_KIND_REPLY;
+		/* wave-uniform counts: ballots land in SGPRs, off the VALU */
+		st_sq += (uint32_t) __popcll(__ballot(kind == SORA_REC_KIND_SQUITTER));
+		st_dirty += (uint32_t) __popcll(__ballot(kind == SORA_REC_KIND_DIRTY));
 	    }
 	}
 	n_rec += total;
@@ -342,34 +341,25 @@ adsb_scan8_kernel(sora_scan_args a) {
 	a.rec_count[group] = n_rec;
 	a.sq_count[group] = n_sq;
     }
-    /* statistics: st_cand is workgroup-uniform, the others per lane */
+    /* statistics: st_cand is workgroup-uniform, the others wave-uniform */
     {
-	uint32_t v1 = st_sq, v2 = st_dirty, v3 = st_reply;
-#pragma unroll
-	for (int d = 32; d >= 1; d >>= 1) {
-	    v1 += __shfl_xor(v1, d, 64);
-	    v2 += __shfl_xor(v2, d, 64);
-	    v3 += __shfl_xor(v3, d, 64);
-	}
-	__shared__ uint32_t s_stat[kWaves][3];
+	__shared__ uint32_t s_stat[kWaves][2];
 	if (lane == 0) {
-	    s_stat[wave][0] = v1;
-	    s_stat[wave][1] = v2;
-	    s_stat[wave][2] = v3;
+	    s_stat[wave][0] = st_sq;
+	    s_stat[wave][1] = st_dirty;
 	}
 	__syncthreads();
 	if (tid == 0) {
-	    uint64_t t1 = 0, t2 = 0, t3 = 0;
+	    uint64_t t1 = 0, t2 = 0;
 	    for (int w = 0; w < kWaves; w++) {
 		t1 += s_stat[w][0];
 		t2 += s_stat[w][1];
-		t3 += s_stat[w][2];
 	    }
 	    uint64_t *st = a.stats + (uint64_t) group * SORA_STAT_WORDS;
 	    st[SORA_STAT_CANDIDATES] = st_cand;
 	    st[SORA_STAT_SQUITTERS] = t1;
 	    st[SORA_STAT_DIRTY] = t2;
-	    st[SORA_STAT_REPLIES] = t3;
+	    st[SORA_STAT_REPLIES] = st_cand - t1 - t2;
 #ifdef SORA_SCAN_STAMPS
 	    for (int i = 0; i < 8; i++)
 		st[SORA_STAT_WORDS_BASE + i] = st_t[i];
@@ -766,7 +756,7 @@ sora_scan_tiles(uint64_t n_scan, int encoding) {
 uint32_t
 sora_scan_lds_bytes(int encoding) {
     (void) encoding;
-    return (uint32_t) ((SORA_M_DWORDS + 4 * SORA_WORDS + kWaves + kWaves * 3) * 4);
+    return (uint32_t) ((SORA_M_DWORDS + 4 * SORA_WORDS + kWaves + kWaves * 2) * 4);
 }
 
 hipError_t

@@ -89,7 +89,63 @@ sora_mag2_pack8(uint32_t iq, uint32_t flip) {
     return m0 | (m1 << 16);		/* each <= 32768 */
 }
 
+/*
+ * Four dwords (eight samples) at once, the form the scan kernel uses.  Per
+ * dword x (after the flip): T = dot4(x, x) = M0 + M1, H = dot4(x, x with its
+ * low half cleared) = M1, packed = T + 65535 * H = M0 + 65536 * M1: five VALU
+ * instructions per dword.  The dot products are written as the VOP3P
+ * v_dot4_i32_i8 with an inline 0 accumulator (the builtin picks the
+ * accumulating VOP2 form and pays a v_mov 0 each).  gfx90a+ does not
+ * interlock a dot result against the next VALU instructions (LLVM inserts
+ * 3 wait states for its own dots, DotWriteDifferentVALURead); inside this
+ * block every result is read at least 3 instructions, and overwritten at
+ * least 4 instructions, after the dot that wrote it.
+ */
+SORA_HD void
+sora_mag2_pack8x4(const uint32_t v[4], uint32_t flip, uint32_t m[4]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t x0 = v[0] ^ flip, x1 = v[1] ^ flip, x2 = v[2] ^ flip,
+	    x3 = v[3] ^ flip;
+    const uint32_t h0 = x0 & 0xffff0000u, h1 = x1 & 0xffff0000u,
+	    h2 = x2 & 0xffff0000u, h3 = x3 & 0xffff0000u;
+    uint32_t t0, t1, t2, t3, g0, g1, g2, g3;
+    asm("v_dot4_i32_i8 %0, %8, %8, 0\n\t"
+	"v_dot4_i32_i8 %4, %8, %12, 0\n\t"
+	"v_dot4_i32_i8 %1, %9, %9, 0\n\t"
+	"v_dot4_i32_i8 %5, %9, %13, 0\n\t"
+	"v_dot4_i32_i8 %2, %10, %10, 0\n\t"
+	"v_dot4_i32_i8 %6, %10, %14, 0\n\t"
+	"v_dot4_i32_i8 %3, %11, %11, 0\n\t"
+	"v_dot4_i32_i8 %7, %11, %15, 0\n\t"
+	"v_mad_u32_u24 %0, %4, %16, %0\n\t"
+	"v_mad_u32_u24 %1, %5, %16, %1\n\t"
+	"v_mad_u32_u24 %2, %6, %16, %2\n\t"
+	"v_mad_u32_u24 %3, %7, %16, %3"
+	: "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3),
+	  "=&v"(g0), "=&v"(g1), "=&v"(g2), "=&v"(g3)
+	: "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(h0), "v"(h1), "v"(h2), "v"(h3),
+	  "s"(0xffffu));
+    m[0] = t0; m[1] = t1; m[2] = t2; m[3] = t3;
+#else
+    for (int i = 0; i < 4; i++)
+	m[i] = sora_mag2_pack8(v[i], flip);
+#endif
+}
+
 /* ---- packed 16-bit arithmetic: one VALU instruction per pair on gfx950 ---- */
+
+/* acc | (v << sh): one v_lshl_or_b32 (left alone, the compiler re-associates a
+ * run of these into shift + shift + v_or3, three instructions per two bits) */
+SORA_HD uint32_t
+sora_shl_or(uint32_t v, int sh, uint32_t acc) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t r;
+    asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "n"(sh), "v"(acc));
+    return r;
+#else
+    return acc | (v << sh);
+#endif
+}
 
 /* per half: a - b, saturating at 0 (v_pk_sub_u16 ... clamp) */
 SORA_HD uint32_t
@@ -174,9 +230,9 @@ sora_lane_compare(const uint32_t *P, uint32_t *up, uint32_t *down, uint32_t *c) 
 	uint32_t u = sora_pk_min(sora_pk_sub_sat(S[s], P[s]), one);
 	uint32_t d = sora_pk_min(sora_pk_sub_sat(P[s], S[s]), one);
 	uint32_t k = sora_pk_min(sora_pk_sub_sat(P[s], W[s + 2]), one);
-	acc_u |= u << (15 - s);
-	acc_d |= d << (15 - s);
-	acc_c |= k << (15 - s);
+	acc_u = sora_shl_or(u, 15 - s, acc_u);
+	acc_d = sora_shl_or(d, 15 - s, acc_d);
+	acc_c = sora_shl_or(k, 15 - s, acc_c);
     }
     *up = acc_u;
     *down = acc_d;
