@@ -170,6 +170,16 @@ def main():
 
     counts = ctx.counts()
     kernel_ms = float(np.mean(scan_ms))
+    # HBM bytes per launch from the PMC passes of this same workload
+    # (tools/hbm_traffic.py: FETCH_SIZE x2 + WRITE_SIZE); null if none matches
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as fh:
+            entry = json.load(fh).get(f"adsb_scan8_kernel:{n_local * BYTES_PER_SAMPLE}")
+        if entry:
+            traffic = round(entry["traffic_bytes"])
+    except (OSError, ValueError):
+        pass
     achieved = n_local * BYTES_PER_SAMPLE / (kernel_ms * 1e-3) / 1e9
 
     line = {
@@ -189,7 +199,7 @@ def main():
         },
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "kernel": "adsb_scan8_kernel", "kernel_ms": round(kernel_ms, 4),
             "algorithmic_bytes": n_local * BYTES_PER_SAMPLE,
         },
