@@ -175,7 +175,7 @@ def main():
     traffic = None
     try:
         with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as fh:
-            entry = json.load(fh).get(f"adsb_scan8_kernel:{n_local * BYTES_PER_SAMPLE}")
+            entry = json.load(fh).get(f"adsb_scan_kernel:{n_local * BYTES_PER_SAMPLE}")
         if entry:
             traffic = round(entry["traffic_bytes"])
     except (OSError, ValueError):
@@ -200,7 +200,7 @@ def main():
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-            "kernel": "adsb_scan8_kernel", "kernel_ms": round(kernel_ms, 4),
+            "kernel": "adsb_scan_kernel<false> (uc8/sc8)", "kernel_ms": round(kernel_ms, 4),
             "algorithmic_bytes": n_local * BYTES_PER_SAMPLE,
         },
     }

@@ -3,8 +3,7 @@
  *
  * CPU restatement of the reference ADS-B chain as functions of a whole
  * sample array.  Build with -ffp-contract=off: the reference is compiled
- * as ISO C99 (configure:58), which forbids contraction, and the sc16
- * magnitude below is only well defined without it.
+ * as ISO C99 (configure:58), which forbids contraction.
  */
 #include "adsb_oracle.h"
 
@@ -47,18 +46,21 @@ oracle_magnitude(const void *iq, size_t nbytes, int encoding, float *m) {
 	return n;
     }
     case ORACLE_ENC_SC16: {
-	/* same formula with radio-file.c:140 scaling (s / 32768); each
-	 * product and the sum round to float separately (no contraction) */
+	/*
+	 * radio-file.c:140 scales sc16 by 1/32768; the reference never routes
+	 * it into ADS-B, so the magnitude is a definition of this build
+	 * (SURVEY.md section 8a, sc16 note; parity unpinned): the exact integer
+	 * I^2 + Q^2 (< 2^32), ONE correctly rounded conversion to float, and an
+	 * exact power-of-two scale.  It differs from squaring and adding in
+	 * float by at most 1 ulp and does not depend on contraction.
+	 */
 	const unsigned char *b = iq;
 	n = nbytes / 4;
 	for (i = 0; i < n; i++) {
-	    int16_t vi = (int16_t) (b[4 * i] | (b[4 * i + 1] << 8));
-	    int16_t vq = (int16_t) (b[4 * i + 2] | (b[4 * i + 3] << 8));
-	    float re = vi / 32768.f;
-	    float im = vq / 32768.f;
-	    float re2 = re * re;
-	    float im2 = im * im;
-	    m[i] = re2 + im2;
+	    int32_t vi = (int16_t) (b[4 * i] | (b[4 * i + 1] << 8));
+	    int32_t vq = (int16_t) (b[4 * i + 2] | (b[4 * i + 3] << 8));
+	    uint32_t sum = (uint32_t) (vi * vi) + (uint32_t) (vq * vq);
+	    m[i] = (float) sum * (1.0f / 1073741824.0f);
 	}
 	return n;
     }

@@ -211,9 +211,10 @@ sora_adsb_create(sora_adsb_ctx **out, int device, const sora_adsb_config *cfg) {
     HIP_TRY(ctx, hipEventCreate(&ctx->ev_scan_begin));
     HIP_TRY(ctx, hipEventCreate(&ctx->ev_scan_end));
 
-    /* three 45 KB workgroups of 512 threads fit the 160 KB of LDS of a CU */
+    /* the scan kernels run sora_scan_groups_per_cu() workgroups on every CU
+     * (what their LDS lets a CU hold): at most 4 */
     ctx->cus = prop.multiProcessorCount > 0? (uint32_t) prop.multiProcessorCount : 1;
-    ctx->max_groups = ctx->cus * 3;
+    ctx->max_groups = ctx->cus * 4;
     ctx->max_regions = sora_filter_regions(ctx->max_groups);
 
     const uint64_t n = cfg->max_chunk_samples;
@@ -259,9 +260,6 @@ sora_adsb_scan(sora_adsb_ctx *ctx, const void *d_iq, size_t nbytes, int encoding
     const int bps = bytes_per_sample(encoding);
     if (bps == 0)
 	return fail(ctx, SORA_ERR_INVALID, "unknown encoding %d", encoding);
-    if (encoding == SORA_ENC_SC16)
-	return fail(ctx, SORA_ERR_INVALID,
-		"sc16 scan is not built yet (SURVEY.md section 8f.2)");
     if (d_iq == nullptr && nbytes != 0)
 	return fail(ctx, SORA_ERR_INVALID, "null IQ pointer");
     if ((reinterpret_cast<uintptr_t>(d_iq) & 15) != 0)
@@ -282,7 +280,7 @@ sora_adsb_scan(sora_adsb_ctx *ctx, const void *d_iq, size_t nbytes, int encoding
     if (n_owned < n_scan)
 	n_scan = n_owned;
     const uint64_t n_tiles = sora_scan_tiles(n_scan, encoding);
-    uint32_t groups = ctx->max_groups;
+    uint32_t groups = ctx->cus * sora_scan_groups_per_cu(encoding);
     if (n_tiles < groups)
 	groups = n_tiles > 0? (uint32_t) n_tiles : 1;
 

@@ -65,7 +65,7 @@ struct sora_resolve_args {
 /* tiles (workgroup passes) a chunk of n_scan positions needs */
 uint64_t sora_scan_tiles(uint64_t n_scan, int encoding);
 /* LDS bytes / thread count of the scan kernel, for documentation and tests */
-uint32_t sora_scan_lds_bytes(int encoding);
+uint32_t sora_scan_groups_per_cu(int encoding);
 
 hipError_t sora_launch_scan(const struct sora_scan_args *a, uint32_t groups,
 	hipStream_t stream);

@@ -32,17 +32,37 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int kThreads = SORA_TILE_THREADS;
-constexpr int kWaves = kThreads / 64;
-constexpr int kLoads = SORA_TILE_SAMPLES * 2 / 16 / kThreads;	/* 16-byte loads per lane */
 constexpr int kSmall = 256;		/* block size of the list kernels */
-/* the queue (u16 tile-local positions) and the CRC table reuse the M buffer
- * once phase 2 has consumed it */
-constexpr int kQueueMax = SORA_TILE_POS / 2;		/* p and p+1 never both hit */
-constexpr int kCrcTableDword = 4096;			/* past the queue (4032 dwords) */
-static_assert(kQueueMax * 2 <= kCrcTableDword * 4, "queue overlaps CRC tables");
-static_assert(kCrcTableDword + SORA_CRC_TABLE_WORDS <= SORA_M_DWORDS,
-	"CRC tables outside M buffer");
+
+/*
+ * Tile geometry of the two scan kernels.  The queue (u16 tile-local positions)
+ * and the CRC tables reuse the M buffer once phase 2 has consumed it.
+ */
+template <bool kWide> struct tile_geom;
+template <> struct tile_geom<false> {		/* uc8, sc8: 16-bit magnitudes */
+    static constexpr int threads = SORA_TILE_THREADS;
+    static constexpr int own_lanes = SORA_OWN_LANES;
+    static constexpr int tile_pos = SORA_TILE_POS;
+    static constexpr int tile_bytes = SORA_TILE_SAMPLES * 2;
+    static constexpr int bytes_per_sample = 2;
+    static constexpr int lane_stride = SORA_LANE_STRIDE;
+    static constexpr int m_dwords = SORA_M_DWORDS;
+    static constexpr int m_tail = 4;		/* zeroed dwords behind the last lane */
+    static constexpr int words = SORA_WORDS;
+    static constexpr int waves_per_simd = 6;	/* 3 workgroups of 8 waves per CU */
+};
+template <> struct tile_geom<true> {		/* sc16: 32-bit magnitudes */
+    static constexpr int threads = SORA16_TILE_THREADS;
+    static constexpr int own_lanes = SORA16_OWN_LANES;
+    static constexpr int tile_pos = SORA16_TILE_POS;
+    static constexpr int tile_bytes = SORA16_TILE_SAMPLES * 4;
+    static constexpr int bytes_per_sample = 4;
+    static constexpr int lane_stride = SORA16_LANE_STRIDE;
+    static constexpr int m_dwords = SORA16_M_DWORDS;
+    static constexpr int m_tail = SORA16_LOOKAHEAD;
+    static constexpr int words = SORA16_WORDS;
+    static constexpr int waves_per_simd = 4;	/* 4 workgroups of 4 waves per CU */
+};
 constexpr int kCrcCopies = SORA_CRC_TABLE_WORDS / 4;	/* 16-byte pieces of the tables */
 
 /* the sliced CRC tables (adsb_tile.h), built at compile time; every tile
@@ -126,15 +146,24 @@ wave_inclusive_scan(uint32_t v) {
 #define STAMP_WAIT_LDS()
 #endif
 
-/* 6 waves per SIMD = three 8-wave workgroups per CU (their LDS fits): <= 80 VGPRs */
-__global__ void __launch_bounds__(kThreads, 6)
-adsb_scan8_kernel(sora_scan_args a) {
-    __shared__ __attribute__((aligned(16))) uint32_t s_m[SORA_M_DWORDS];
+template <bool kWide>
+__global__ void __launch_bounds__(tile_geom<kWide>::threads, tile_geom<kWide>::waves_per_simd)
+adsb_scan_kernel(sora_scan_args a) {
+    using G = tile_geom<kWide>;
+    constexpr int kThreads = G::threads;
+    constexpr int kWaves = kThreads / 64;
+    constexpr int kLoads = G::tile_bytes / 16 / kThreads;	/* 16-byte loads per lane */
+    constexpr int kTilePos = G::tile_pos;
+    constexpr int kQueueMax = kTilePos / 2;		/* p and p+1 never both hit */
+    constexpr int kCrcTableDword = (kQueueMax / 2 + 63) & ~63;	/* past the queue */
+    static_assert(kCrcTableDword + SORA_CRC_TABLE_WORDS <= G::m_dwords,
+	    "CRC tables outside M buffer");
+
+    __shared__ __attribute__((aligned(16))) uint32_t s_m[G::m_dwords];
     /* bit arrays, written as 16-bit halves (one per lane), read as 32-bit words */
-    __shared__ __attribute__((aligned(4))) uint16_t s_nue[2 * SORA_WORDS];
-    __shared__ __attribute__((aligned(4))) uint16_t s_nuo[2 * SORA_WORDS];
-    __shared__ __attribute__((aligned(4))) uint16_t s_de[2 * SORA_WORDS];
-    __shared__ __attribute__((aligned(4))) uint16_t s_do[2 * SORA_WORDS];
+    __shared__ __attribute__((aligned(4))) uint16_t s_bits[4][2 * G::words];
+    uint16_t *const s_nue = s_bits[0], *const s_nuo = s_bits[1];
+    uint16_t *const s_de = s_bits[2], *const s_do = s_bits[3];
     __shared__ uint32_t s_part[kWaves];
     __shared__ uint32_t s_sq_count;
 
@@ -159,58 +188,86 @@ adsb_scan8_kernel(sora_scan_args a) {
     const uint32_t *w_nuo = reinterpret_cast<const uint32_t *>(s_nuo);
 
     for (uint64_t tile = tile_begin; tile < tile_end; tile++) {
-	const uint64_t tile_start = tile * SORA_TILE_POS;
+	const uint64_t tile_start = tile * kTilePos;
+	/* the thread index, made opaque once per tile: LDS addresses derived from
+	 * it are then formed inside the loop as one register plus the immediate
+	 * offset field of the ds instructions; hoisted out of the loop they are a
+	 * dozen VGPRs of their own, which at 80 VGPRs means spills */
+	uint32_t t = tid;
+	asm volatile("" : "+v"(t));
 	STAMP_BEGIN();
 
 	/* ---- phase 1: load, magnitude, LDS ---- */
 	{
-	    uint64_t left = (a.n_samples - tile_start) * 2;	/* bytes */
+	    uint64_t left = (a.n_samples - tile_start) * G::bytes_per_sample;
 	    left = (left + 3) & ~3ull;		/* see sora_adsb_scan(): an odd
 						 * sample count reads its last dword whole */
-	    uint32_t span = left < (uint64_t) SORA_TILE_SAMPLES * 2?
-		    (uint32_t) left : (uint32_t) SORA_TILE_SAMPLES * 2;
+	    uint32_t span = left < (uint64_t) G::tile_bytes?
+		    (uint32_t) left : (uint32_t) G::tile_bytes;
 	    auto rsrc = __builtin_amdgcn_make_buffer_rsrc(
-		    const_cast<uint8_t *>(a.iq) + tile_start * 2, 0, span,
-		    0x00020000);
+		    const_cast<uint8_t *>(a.iq) + tile_start * G::bytes_per_sample, 0,
+		    span, 0x00020000);
 	    u32x4 v[kLoads];
 #pragma unroll
 	    for (int r = 0; r < kLoads; r++)
-		v[r] = __builtin_amdgcn_raw_buffer_load_b128(rsrc,
-			(r * kThreads + tid) * 16, 0, 0);
+		v[r] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, t * 16,
+			r * kThreads * 16, 0);
 	    STAMP_WAIT_VM();
 	    STAMP(0);			/* HBM latency of the tile's loads */
 #pragma unroll
 	    for (int r = 0; r < kLoads; r++) {
-		uint32_t pair = (r * kThreads + tid) * 4;
+		/* this load's four M dwords in lane-run order: M dword
+		 * (r * kThreads + t) * 4 and on; one load instruction fills
+		 * whole lane runs, so r contributes a constant */
 		const uint32_t raw[4] = {v[r][0], v[r][1], v[r][2], v[r][3]};
 		uint32_t mm[4];
-		sora_mag2_pack8x4(raw, flip, mm);
+		uint32_t at;
+		if constexpr (kWide) {
+		    sora_mag_sc16x4(raw, mm);		/* one dword per sample */
+		    /* 32 + 4 dwords per lane */
+		    at = r * (kThreads * 4 / 32) * G::lane_stride + 4 * t + 4 * (t >> 3);
+		} else {
+		    sora_mag2_pack8x4(raw, flip, mm);	/* one dword per pair */
+		    /* 16 + 4 dwords per lane */
+		    at = r * (kThreads * 4 / 16) * G::lane_stride + 4 * t + 4 * (t >> 2);
+		}
 		const u32x4 m = {mm[0], mm[1], mm[2], mm[3]};
-		*reinterpret_cast<u32x4 *>(&s_m[pair + 4 * (pair >> 4)]) = m;
+		*reinterpret_cast<u32x4 *>(&s_m[at]) = m;
 	    }
-	    if (tid < 4)
-		s_m[kThreads * SORA_LANE_STRIDE + tid] = 0;
+	    if (tid < G::m_tail)
+		s_m[kThreads * G::lane_stride + tid] = 0;
 	}
 	STAMP_WAIT_LDS();
 	STAMP(1);			/* magnitudes + LDS stores */
 	__syncthreads();
 	STAMP(2);			/* barrier 1 */
 
-	/* ---- phase 2: compare bits of this lane's 16 pairs ---- */
+	/* ---- phase 2: compare bits of this lane's 32 positions ---- */
 	uint32_t up, down, cc;
-	{
+	if constexpr (kWide) {
+	    uint32_t M[SORA_LANE_POS + SORA16_LOOKAHEAD];
+#pragma unroll
+	    for (int i = 0; i < (SORA_LANE_POS + SORA16_LOOKAHEAD) / 4; i++) {
+		/* the next lane's run starts 36 dwords on: dwords 32..35 are padding */
+		const uint32_t at = t * G::lane_stride + (i < 8? 4 * i : 4 * i + 4);
+		u32x4 q4 = *reinterpret_cast<const u32x4 *>(&s_m[at]);
+		M[4 * i] = q4[0]; M[4 * i + 1] = q4[1];
+		M[4 * i + 2] = q4[2]; M[4 * i + 3] = q4[3];
+	    }
+	    sora_lane_compare32(M, &up, &down, &cc);
+	} else {
 	    uint32_t P[SORA_LANE_STRIDE];
 #pragma unroll
 	    for (int i = 0; i < 4; i++) {
-		u32x4 t = *reinterpret_cast<const u32x4 *>(
-			&s_m[tid * SORA_LANE_STRIDE + 4 * i]);
-		P[4 * i] = t[0]; P[4 * i + 1] = t[1];
-		P[4 * i + 2] = t[2]; P[4 * i + 3] = t[3];
+		u32x4 q4 = *reinterpret_cast<const u32x4 *>(
+			&s_m[t * SORA_LANE_STRIDE + 4 * i]);
+		P[4 * i] = q4[0]; P[4 * i + 1] = q4[1];
+		P[4 * i + 2] = q4[2]; P[4 * i + 3] = q4[3];
 	    }
 	    {
-		u32x4 t = *reinterpret_cast<const u32x4 *>(
-			&s_m[(tid + 1) * SORA_LANE_STRIDE]);
-		P[16] = t[0]; P[17] = t[1]; P[18] = t[2]; P[19] = t[3];
+		u32x4 q4 = *reinterpret_cast<const u32x4 *>(
+			&s_m[t * SORA_LANE_STRIDE + SORA_LANE_STRIDE]);
+		P[16] = q4[0]; P[17] = q4[1]; P[18] = q4[2]; P[19] = q4[3];
 	    }
 	    sora_lane_compare(P, &up, &down, &cc);
 	}
@@ -219,10 +276,10 @@ adsb_scan8_kernel(sora_scan_args a) {
 	 * of a little-endian word, i.e. at 16-bit index g ^ 1 */
 	const uint32_t nue16 = ~up & 0xffffu, nuo16 = (~up) >> 16;
 	const uint32_t de16 = down & 0xffffu, do16 = down >> 16;
-	s_nue[tid ^ 1] = (uint16_t) nue16;
-	s_nuo[tid ^ 1] = (uint16_t) nuo16;
-	s_de[tid ^ 1] = (uint16_t) de16;
-	s_do[tid ^ 1] = (uint16_t) do16;
+	s_nue[t ^ 1] = (uint16_t) nue16;
+	s_nuo[t ^ 1] = (uint16_t) nuo16;
+	s_de[t ^ 1] = (uint16_t) de16;
+	s_do[t ^ 1] = (uint16_t) do16;
 	if (tid < 2) {
 	    s_nue[kThreads + tid] = 0;
 	    s_nuo[kThreads + tid] = 0;
@@ -234,27 +291,29 @@ adsb_scan8_kernel(sora_scan_args a) {
 
 	/* ---- phase 3: predicate words, ordered queue of hits ---- */
 	/* the CRC tables for phase 4: fetched now, stored once the scan is done */
-	u32x4 tab0, tab1 = {0, 0, 0, 0};
+	constexpr int kTabs = (kCrcCopies + kThreads - 1) / kThreads;
+	u32x4 tab[kTabs];
 	{
 	    const u32x4 *src = reinterpret_cast<const u32x4 *>(g_crc_slices.w);
-	    tab0 = src[tid];
-	    if (tid + kThreads < kCrcCopies)
-		tab1 = src[tid + kThreads];
+#pragma unroll
+	    for (int c = 0; c < kTabs; c++)
+		if ((c + 1) * kThreads <= kCrcCopies || c * kThreads + tid < kCrcCopies)
+		    tab[c] = src[c * kThreads + tid];
 	}
 	uint32_t pe, po;
 	{
 	    const uint64_t left = a.n_scan - tile_start;
-	    const uint32_t nx = (tid + 1) ^ 1;	/* the next lane's half */
+	    const uint32_t nx = (t + 1) ^ 1;	/* the next lane's half */
 
 	    sora_lane_predicate((nue16 << 16) | s_nue[nx], (nuo16 << 16) | s_nuo[nx],
 		    (de16 << 16) | s_de[nx], (do16 << 16) | s_do[nx],
 		    cc << 16, cc & 0xffff0000u, &pe, &po);
-	    if (left >= (uint64_t) SORA_TILE_POS) {	/* all but the last tile */
-		if (tid >= SORA_OWN_LANES)
+	    if (left >= (uint64_t) kTilePos) {	/* all but the last tile */
+		if (tid >= G::own_lanes)
 		    pe = po = 0;
 	    } else {
 		uint32_t ve, vo;
-		sora_lane_valid((int) tid, (int64_t) left, &ve, &vo);
+		sora_lane_valid_n((int) tid, (int64_t) left, G::own_lanes, &ve, &vo);
 		pe &= ve;
 		po &= vo;
 	    }
@@ -265,9 +324,10 @@ adsb_scan8_kernel(sora_scan_args a) {
 	const uint32_t incl = wave_inclusive_scan(cnt);
 	if (lane == 63)
 	    s_part[wave] = incl;
-	*reinterpret_cast<u32x4 *>(&s_crc[4 * tid]) = tab0;
-	if (tid + kThreads < kCrcCopies)
-	    *reinterpret_cast<u32x4 *>(&s_crc[4 * (tid + kThreads)]) = tab1;
+#pragma unroll
+	for (int c = 0; c < kTabs; c++)
+	    if ((c + 1) * kThreads <= kCrcCopies || c * kThreads + tid < kCrcCopies)
+		*reinterpret_cast<u32x4 *>(&s_crc[4 * c * kThreads + 4 * t]) = tab[c];
 	if (tid == 0)
 	    s_sq_count = 0;
 	__syncthreads();
@@ -591,10 +651,9 @@ __device__ __forceinline__ float
 magnitude_f32(const uint8_t *iq, uint64_t i, int encoding) {
     /* row a1; float result is exact for the 8-bit encodings */
     if (encoding == SORA_ENC_SC16) {
-	const int16_t *s = reinterpret_cast<const int16_t *>(iq) + 2 * i;
-	float re = (float) s[0] * (1.0f / 32768.0f);
-	float im = (float) s[1] * (1.0f / 32768.0f);
-	return __fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im));
+	/* the definition of sora_mag_sc16 (adsb_tile.h), scaled by 2^-30 */
+	const uint32_t w = reinterpret_cast<const uint32_t *>(iq)[i];
+	return __uint_as_float(sora_mag_sc16(w)) * (1.0f / 1073741824.0f);
     }
     int vi, vq;
     if (encoding == SORA_ENC_UC8) {
@@ -749,22 +808,31 @@ grid_for(uint64_t n, uint32_t block) {
 
 uint64_t
 sora_scan_tiles(uint64_t n_scan, int encoding) {
-    (void) encoding;
-    return (n_scan + SORA_TILE_POS - 1) / SORA_TILE_POS;
+    const uint64_t pos = encoding == SORA_ENC_SC16? SORA16_TILE_POS : SORA_TILE_POS;
+    return (n_scan + pos - 1) / pos;
 }
 
 uint32_t
-sora_scan_lds_bytes(int encoding) {
-    (void) encoding;
-    return (uint32_t) ((SORA_M_DWORDS + 4 * SORA_WORDS + kWaves + kWaves * 2) * 4);
+sora_scan_groups_per_cu(int encoding) {
+    /* workgroups of one CU: bounded by LDS (45 KB and 39 KB per workgroup) */
+    return encoding == SORA_ENC_SC16? 4 : 3;
 }
 
 hipError_t
 sora_launch_scan(const sora_scan_args *a, uint32_t groups, hipStream_t stream) {
-    if (a->encoding != SORA_ENC_UC8 && a->encoding != SORA_ENC_SC8)
+    switch (a->encoding) {
+    case SORA_ENC_UC8:
+    case SORA_ENC_SC8:
+	hipLaunchKernelGGL(adsb_scan_kernel<false>, dim3(groups),
+		dim3(tile_geom<false>::threads), 0, stream, *a);
+	break;
+    case SORA_ENC_SC16:
+	hipLaunchKernelGGL(adsb_scan_kernel<true>, dim3(groups),
+		dim3(tile_geom<true>::threads), 0, stream, *a);
+	break;
+    default:
 	return hipErrorInvalidValue;
-    hipLaunchKernelGGL(adsb_scan8_kernel, dim3(groups), dim3(kThreads), 0,
-	    stream, *a);
+    }
     return hipGetLastError();
 }
 

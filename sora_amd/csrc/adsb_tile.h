@@ -50,6 +50,18 @@
  * words, MSB first: lane 2w is the top half of word w */
 #define SORA_WORDS		(SORA_TILE_THREADS / 2 + 1)
 
+/* ---- tile geometry for sc16 (32-bit magnitudes): 256 lanes of 32 positions,
+ * lane g's 32 dwords of M start at dword 36*g (36 = 4*9, 9 odd: the 16-byte
+ * stores and reads stay bank-conflict free) ---- */
+#define SORA16_TILE_THREADS	256
+#define SORA16_OWN_LANES	248
+#define SORA16_TILE_POS		(SORA16_OWN_LANES * SORA_LANE_POS)	/* 7936 */
+#define SORA16_TILE_SAMPLES	(SORA16_TILE_THREADS * SORA_LANE_POS)	/* 8192 */
+#define SORA16_LANE_STRIDE	36
+#define SORA16_M_DWORDS		(SORA16_TILE_THREADS * SORA16_LANE_STRIDE + 8)
+#define SORA16_WORDS		(SORA16_TILE_THREADS / 2 + 1)
+#define SORA16_LOOKAHEAD	8		/* dwords of the next lane a lane reads */
+
 #define SORA_WINDOW		240
 
 /* record: kind[63:60] | chunk-local position[59:24] | address or syndrome[23:0] */
@@ -129,6 +141,57 @@ sora_mag2_pack8x4(const uint32_t v[4], uint32_t flip, uint32_t m[4]) {
 #else
     for (int i = 0; i < 4; i++)
 	m[i] = sora_mag2_pack8(v[i], flip);
+#endif
+}
+
+/*
+ * sc16 (I, Q little-endian int16 in one dword): the magnitude is DEFINED as
+ * m = (float) (uint32) (I^2 + Q^2) * 2^-30, one correctly rounded conversion
+ * of the exact integer (SURVEY.md section 8a, sc16 note; the reference has no
+ * sc16 path into ADS-B).  Returned: the bit pattern of the unscaled float
+ * (float) (I^2 + Q^2).  Non-negative floats order like their bit patterns and
+ * the power-of-two scale changes no comparison, so the kernel compares these
+ * words as integers; they are below 2^31, so a difference keeps its sign.
+ */
+SORA_HD uint32_t
+sora_float_bits(float f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __float_as_uint(f);
+#else
+    union { float f; uint32_t u; } c;
+    c.f = f;
+    return c.u;
+#endif
+}
+
+SORA_HD uint32_t
+sora_mag_sc16(uint32_t iq) {
+    const int32_t i = (int16_t) (iq & 0xffffu), q = (int16_t) (iq >> 16);
+    const uint32_t sum = (uint32_t) (i * i) + (uint32_t) (q * q);	/* <= 2^31 */
+
+    return sora_float_bits((float) sum);
+}
+
+/* four samples at once: v_dot2_i32_i16 with an inline 0 accumulator, then the
+ * conversions; the same wait-state distances as sora_mag2_pack8x4 */
+SORA_HD void
+sora_mag_sc16x4(const uint32_t v[4], uint32_t m[4]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t t0, t1, t2, t3;
+    asm("v_dot2_i32_i16 %0, %4, %4, 0\n\t"
+	"v_dot2_i32_i16 %1, %5, %5, 0\n\t"
+	"v_dot2_i32_i16 %2, %6, %6, 0\n\t"
+	"v_dot2_i32_i16 %3, %7, %7, 0\n\t"
+	"v_cvt_f32_u32_e32 %0, %0\n\t"
+	"v_cvt_f32_u32_e32 %1, %1\n\t"
+	"v_cvt_f32_u32_e32 %2, %2\n\t"
+	"v_cvt_f32_u32_e32 %3, %3"
+	: "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+	: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+    m[0] = t0; m[1] = t1; m[2] = t2; m[3] = t3;
+#else
+    for (int i = 0; i < 4; i++)
+	m[i] = sora_mag_sc16(v[i]);
 #endif
 }
 
@@ -239,6 +302,47 @@ sora_lane_compare(const uint32_t *P, uint32_t *up, uint32_t *down, uint32_t *c) 
     *c = acc_c;
 }
 
+/* (acc << 1) | (the sign of d): one v_alignbit_b32 */
+SORA_HD uint32_t
+sora_shift_in_sign(uint32_t acc, uint32_t d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbit(acc, d, 31);
+#else
+    return (acc << 1) | (d >> 31);
+#endif
+}
+
+SORA_HD uint32_t
+sora_max3(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t m = a > b? a : b;
+    return m > c? m : c;		/* v_max3_u32 */
+}
+
+/*
+ * The same three bit sets from 32-bit magnitudes (sc16): M[0..31] are the
+ * lane's positions, M[32..38] the next lane's first seven.  Same result layout
+ * as sora_lane_compare: even positions in the low half, odd in the high half,
+ * pair s at bit 15-s.  Seven VALU instructions per position.
+ */
+SORA_HD void
+sora_lane_compare32(const uint32_t *M, uint32_t *up, uint32_t *down, uint32_t *c) {
+    uint32_t u[2] = {0, 0}, d[2] = {0, 0}, k[2] = {0, 0};
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int i = 0; i < SORA_LANE_POS; i++) {
+	const uint32_t a = M[i], b = M[i + 1];
+	const uint32_t w = sora_max3(M[i + 4], M[i + 5], M[i + 6]);
+	u[i & 1] = sora_shift_in_sign(u[i & 1], a - b);	/* b > a */
+	d[i & 1] = sora_shift_in_sign(d[i & 1], b - a);	/* b < a */
+	k[i & 1] = sora_shift_in_sign(k[i & 1], w - a);	/* a > w */
+    }
+    *up = u[0] | (u[1] << 16);
+    *down = d[0] | (d[1] << 16);
+    *c = k[0] | (k[1] << 16);
+}
+
 /*
  * Candidate masks of one lane.  Arguments are 32-bit windows of the MSB-first
  * bit arrays: the lane's own 16 elements in the top half, the next lane's 16
@@ -272,13 +376,19 @@ sora_first_elements(int64_t count) {
  * tile that are to be scanned) and the lane is not a halo lane.
  */
 SORA_HD void
-sora_lane_valid(int g, int64_t limit, uint32_t *valid_e, uint32_t *valid_o) {
+sora_lane_valid_n(int g, int64_t limit, int own_lanes, uint32_t *valid_e,
+	uint32_t *valid_o) {
     int64_t left = limit - (int64_t) g * SORA_LANE_POS;
 
-    if (g >= SORA_OWN_LANES)
+    if (g >= own_lanes)
 	left = 0;
     *valid_e = sora_first_elements((left + 1) >> 1);
     *valid_o = sora_first_elements(left >> 1);
+}
+
+SORA_HD void
+sora_lane_valid(int g, int64_t limit, uint32_t *valid_e, uint32_t *valid_o) {
+    sora_lane_valid_n(g, limit, SORA_OWN_LANES, valid_e, valid_o);
 }
 
 /* ---- a7..a9: one candidate out of the NU bit arrays ---- */

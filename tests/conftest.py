@@ -54,6 +54,9 @@ def emulator():
     L.emul_scan8.restype = C.c_size_t
     L.emul_scan8.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_int,
                              C.c_void_p, C.c_size_t]
+    L.emul_scan16.restype = C.c_size_t
+    L.emul_scan16.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int,
+                              C.c_void_p, C.c_size_t]
     return L
 
 

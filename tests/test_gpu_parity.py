@@ -256,3 +256,64 @@ def test_config1_size_properties():
                               base_position=int(s), n_owned=int(e - s))
             out.append(ctx.collect())
     assert np.concatenate(out).tobytes() == a.tobytes()
+
+
+# ---- sc16: adsb_scan_kernel<true>.  Parity unpinned by
+# the reference (it has no sc16 route into ADS-B); the oracle's definition of the
+# sc16 magnitude is the build's own, see oracle/adsb_oracle.c.
+
+def sc16_noise(seed, n, sigma):
+    rng = np.random.default_rng(seed)
+    v = np.clip(np.rint(rng.normal(0, sigma, size=2 * n)), -32768, 32767)
+    return v.astype("<i2").tobytes()
+
+
+@pytest.mark.parametrize("sigma", [3, 400, 8000, 30000])
+def test_sc16_noise_all_fields(sigma):
+    """sigma 8000 and 30000 put I^2+Q^2 past 2^24 (float rounding ties, clipping)."""
+    raw = sc16_noise(40 + sigma, 200003, sigma)
+    want = ob.scan(raw, ENC_SC16)
+    got, counts = gpu_frames(raw, ENC_SC16)
+    assert_same_frames(got, want)
+    assert counts["candidates"] == len(want) > 1000
+
+
+def test_sc16_uniform_bytes():
+    rng = np.random.default_rng(8)
+    raw = rng.integers(0, 256, size=4 * 100001, dtype=np.uint8).tobytes()
+    got, _ = gpu_frames(raw, ENC_SC16)
+    assert_same_frames(got, ob.scan(raw, ENC_SC16))
+
+
+@pytest.mark.parametrize("n", [0, 1, 239, 240, 241, 7936 + 239, 7936 + 240, 8191, 8192,
+                               2 * 7936 + 238])
+def test_sc16_edge_lengths(n):
+    raw = sc16_noise(n, n, 400)
+    got, _ = gpu_frames(raw, ENC_SC16)
+    assert_same_frames(got, ob.scan(raw, ENC_SC16))
+
+
+def test_sc16_config4_traffic():
+    """BASELINE configs[3] in small: dense sc16 traffic, overlapping frames, 20 %
+    of them with one flipped bit (rejected: correction is opt-in, D3)."""
+    p = synth.default_params(4, n_samples=1200000, seed=5)
+    raw = synth.fill_host(p.n_samples, p.encoding, p.seed, synth.make_frames(p)).tobytes()
+    want = ob.scan(raw, ENC_SC16)
+    got, _ = gpu_frames(raw, ENC_SC16)
+    assert_same_frames(got, want)
+    acc, _ = gpu_frames(raw, ENC_SC16, emit=EMIT_ACCEPTED, host=True)
+    assert_same_frames(acc, [c for c in want if c["accepted"]])
+    assert len(acc) > 1000
+
+
+def test_sc16_frames_on_tile_edges():
+    klm = synth.hex_to_bits("8D4840D6202CC371C32CE0576098")
+    T = 7936
+    edges = [T - 241, T + 10, 2 * T - 17, 3 * T - 1, 4 * T, 5 * T + 1, 6 * T - 64,
+             6 * T + 256, 7 * T - 239]
+    table = synth.frame_table([(p, klm, 9000, 0, 112) for p in edges])
+    raw = synth.fill_host(7 * T + 500, ENC_SC16, 99, table).tobytes()
+    want = ob.scan(raw, ENC_SC16)
+    got, _ = gpu_frames(raw, ENC_SC16)
+    assert_same_frames(got, want)
+    assert set(edges) <= {c["position"] for c in got if c["accepted"]}

@@ -33,7 +33,7 @@ def mean_counter(directory, counter, kernel):
 
 def main():
     fetch_dir, write_dir, nbytes = sys.argv[1], sys.argv[2], int(sys.argv[3])
-    kernel = sys.argv[4] if len(sys.argv) > 4 else "adsb_scan8_kernel"
+    kernel = sys.argv[4] if len(sys.argv) > 4 else "adsb_scan_kernel"
     fetch, nf = mean_counter(fetch_dir, "FETCH_SIZE", kernel)
     write, nw = mean_counter(write_dir, "WRITE_SIZE", kernel)
     out = {
