@@ -26,7 +26,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec peak
-BYTES_PER_SAMPLE = 2        # uc8: the algorithmic traffic, SURVEY.md section 8d
+# algorithmic traffic: every input byte once, 2 B per
+# uc8/sc8 sample, 4 B per sc16 sample
 
 
 def parse_args():
@@ -39,6 +40,9 @@ def parse_args():
     ap.add_argument("--cpu-samples", type=float, default=120e6,
                     help="bounded sample for the CPU baseline leg (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--encoding", choices=("uc8", "sc8", "sc16"), default="uc8",
+                    help="uc8 is BASELINE.json's metric; sc8/sc16 are side measurements "
+                         "(sc16 uses the dense configs[3] traffic)")
     ap.add_argument("--force-collective", action="store_true",
                     help="run the N>1 exchange code path even with one rank (rehearsal)")
     return ap.parse_args()
@@ -87,7 +91,8 @@ def main():
     import torch.distributed as dist
 
     import sora_amd
-    from sora_amd import ENC_UC8, FRAME_DTYPE, AdsbContext, synth
+    from sora_amd import FRAME_DTYPE, AdsbContext, synth
+    from sora_amd._lib import BYTES_PER_SAMPLE as BPS, ENCODING_NAMES
     from sora_amd.sharded import ShardedDecoder
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -105,6 +110,8 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=dev)              # RCCL over xGMI
 
+    enc = ENCODING_NAMES[args.encoding]
+    bps = BPS[enc]
     per_gpu = int(args.samples)
     per_gpu -= per_gpu % 8                                   # shard starts stay 16-byte aligned
     total = per_gpu * world
@@ -112,19 +119,20 @@ def main():
     n_local = per_gpu + (0 if last else sora_amd.HALO)
 
     # ---- synthetic capture, generated straight into HBM ----
-    params = synth.default_params(2, n_samples=total)
+    params = synth.default_params(4 if args.encoding == "sc16" else 2, n_samples=total)
+    params.encoding = enc
     frames = synth.make_frames(params)
     first = rank * per_gpu
     lo = np.searchsorted(frames["position"], max(0, first - 240))
     hi = np.searchsorted(frames["position"], first + n_local)
-    d_iq = torch.empty(2 * n_local + 16, dtype=torch.uint8, device=dev)
-    synth.fill_device(d_iq.data_ptr(), n_local, ENC_UC8, params.seed, frames[lo:hi],
+    d_iq = torch.empty(bps * n_local + 16, dtype=torch.uint8, device=dev)
+    synth.fill_device(d_iq.data_ptr(), n_local, enc, params.seed, frames[lo:hi],
                       first=first)
     torch.cuda.synchronize()
 
-    max_frames = per_gpu // 1024 + 65536        # ~3x the injected frame rate
+    max_frames = per_gpu // (64 if args.encoding == "sc16" else 1024) + 65536
     ctx = AdsbContext(n_local, device=local, max_squitters=max_frames,
-                      max_frames=max_frames)
+                      max_frames=max_frames)             # ~3x the injected frame rate
     collective = world > 1 or args.force_collective
     if collective:
         # scan -> squitter-record all-gather -> resolve -> frame-list gather
@@ -139,10 +147,10 @@ def main():
 
     def step():
         if collective:
-            n = sharded.step(d_iq, 2 * n_local, ENC_UC8, first, per_gpu)
+            n = sharded.step(d_iq, bps * n_local, enc, first, per_gpu)
         else:
             ctx.reset()                                      # a new capture: no known planes
-            ctx.submit_device(d_iq, 2 * n_local, ENC_UC8, base_position=first,
+            ctx.submit_device(d_iq, bps * n_local, enc, base_position=first,
                               n_owned=per_gpu)
             n = ctx.collect_into(h_frames)                   # frame list in host memory
         scan_ms.append(ctx.last_scan_ms())
@@ -175,37 +183,42 @@ def main():
     traffic = None
     try:
         with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as fh:
-            entry = json.load(fh).get(f"adsb_scan_kernel:{n_local * BYTES_PER_SAMPLE}")
+            entry = json.load(fh).get(f"adsb_scan_kernel:{args.encoding}:{n_local * bps}")
         if entry:
             traffic = round(entry["traffic_bytes"])
     except (OSError, ValueError):
         pass
-    achieved = n_local * BYTES_PER_SAMPLE / (kernel_ms * 1e-3) / 1e9
+    achieved = n_local * bps / (kernel_ms * 1e-3) / 1e9
 
     line = {
-        "metric": "Msamples/s ADS-B decoded (2MS/s uc8 IQ)",
+        "metric": f"Msamples/s ADS-B decoded (2MS/s {args.encoding} IQ)",
         "value": round(total * args.steps / dt / 1e6, 1),
         "unit": "Msamples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "u8", "data": "synthetic",
+        "dtype": "f32" if args.encoding == "sc16" else "u8", "data": "synthetic",
         "config": {
-            "workload": "configs[1]: 1-hour synthetic 2 MS/s uc8 capture per GPU "
-                        "(DF17/DF11 at mixed SNR), scan + resolve + frame list to host",
-            "samples_per_gpu": per_gpu, "bytes_per_gpu": 2 * n_local,
+            "workload": ("configs[1]: 1-hour synthetic 2 MS/s uc8 capture per GPU "
+                         "(DF17/DF11 at mixed SNR), scan + resolve + frame list to host"
+                         if args.encoding == "uc8" and per_gpu == 7200000000 else
+                         f"side measurement: {per_gpu} samples of {args.encoding} per GPU, "
+                         "scan + resolve + frame list to host"),
+            "samples_per_gpu": per_gpu, "bytes_per_gpu": bps * n_local,
             "injected_frames": int(len(frames)), "frames_out": int(n_frames),
             "candidates_rank0": int(counts["candidates"]),
         },
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-            "kernel": "adsb_scan_kernel<false> (uc8/sc8)", "kernel_ms": round(kernel_ms, 4),
-            "algorithmic_bytes": n_local * BYTES_PER_SAMPLE,
+            "kernel": "adsb_scan_kernel<true> (sc16)" if args.encoding == "sc16"
+                      else "adsb_scan_kernel<false> (uc8/sc8)",
+            "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes": n_local * bps,
         },
     }
 
-    if rank == 0 and world == 1 and not args.no_cpu and args.cpu_samples > 0:
+    if (rank == 0 and world == 1 and not args.no_cpu and args.cpu_samples > 0
+            and args.encoding == "uc8"):          # the reference reads uc8 only
         n_cpu = min(int(args.cpu_samples), per_gpu)
         pos = h_frames["position"][:n_frames]
         in_window = int(np.count_nonzero(pos < n_cpu - 239))

@@ -3,7 +3,7 @@
 
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d F -- python3 bench.py --steps 2 --warmup 1 --no-cpu
     rocprofv3 --pmc WRITE_SIZE --output-format csv -d W -- python3 bench.py --steps 2 --warmup 1 --no-cpu
-    python tools/hbm_traffic.py F W bytes_per_gpu > profiles/hbm_traffic.json
+    python tools/hbm_traffic.py F W uc8 bytes_per_gpu > profiles/hbm_traffic.json
 
 Units and corrections as /opt/skills/guides/MI355X_MICROARCH.md (HBM) says:
 both counters are in KiB; on gfx950 FETCH_SIZE reports half of the bytes of
@@ -32,8 +32,8 @@ def mean_counter(directory, counter, kernel):
 
 
 def main():
-    fetch_dir, write_dir, nbytes = sys.argv[1], sys.argv[2], int(sys.argv[3])
-    kernel = sys.argv[4] if len(sys.argv) > 4 else "adsb_scan_kernel"
+    fetch_dir, write_dir, enc, nbytes = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
+    kernel = sys.argv[5] if len(sys.argv) > 5 else "adsb_scan_kernel"
     fetch, nf = mean_counter(fetch_dir, "FETCH_SIZE", kernel)
     write, nw = mean_counter(write_dir, "WRITE_SIZE", kernel)
     out = {
@@ -44,7 +44,7 @@ def main():
         "traffic_bytes": 2 * fetch * 1024 + write * 1024,
         "correction": "FETCH_SIZE x2 (gfx950, 16 B/lane streaming reads), KiB units",
     }
-    print(json.dumps({f"{kernel}:{nbytes}": out}, indent=1))
+    print(json.dumps({f"{kernel}:{enc}:{nbytes}": out}, indent=1))
 
 
 if __name__ == "__main__":
