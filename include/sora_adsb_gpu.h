@@ -64,6 +64,18 @@ extern "C" {
 #define SORA_FRAME_LONG		0x01	/* 16 <= DF <= 24, plane.c:462 */
 #define SORA_FRAME_SQUITTER	0x02	/* DF 11, 17, 18, plane.c:473 */
 #define SORA_FRAME_ACCEPTED	0x04
+#define SORA_FRAME_CORRECTED	0x08	/* one bit was flipped back (extension, below) */
+
+/*
+ * Options.  SORA_OPT_CORRECT_SINGLE_BIT is SURVEY.md's extension D3 / section
+ * 8 f.3 and is OFF by default: the reference never corrects (plane.c:476).
+ * With it, a DF11/17/18 candidate whose syndrome is that of ONE flipped bit b,
+ * 5 <= b < 56 (DF11) or < 112 (DF17/18), is accepted with that bit flipped
+ * back: bits, address and df are those of the corrected message, syndrome is
+ * the one found before the flip, corrected_bit = b, and its address becomes
+ * known from its position on like any squitter's.
+ */
+#define SORA_OPT_CORRECT_SINGLE_BIT	0x01
 
 /* 48 bytes, what the demodulator + validator know about one frame */
 struct sora_adsb_frame {
@@ -78,7 +90,8 @@ struct sora_adsb_frame {
 			    * M[p+16+2k]+M[p+17+2k], M = I^2+Q^2 in counts;
 			    * amplitude_56 == sum56 * 2^-15 exactly.  0 for sc16 */
     uint8_t df;		   /* bits[0,5) */
-    int8_t corrected_bit;  /* -1: none (the reference never corrects, D3) */
+    int8_t corrected_bit;  /* -1: none (the reference never corrects, D3);
+			    * else see SORA_OPT_CORRECT_SINGLE_BIT */
     uint8_t flags;	   /* SORA_FRAME_* */
     uint8_t reserved;
 };
@@ -90,7 +103,7 @@ struct sora_adsb_config {
     uint64_t max_frames;	/* 0 = max_squitters (EMIT_ACCEPTED) or
 				 * max_candidates (EMIT_CANDIDATES) */
     int32_t emit_mode;		/* SORA_EMIT_* */
-    int32_t reserved;
+    int32_t options;		/* SORA_OPT_*, 0 = the reference's behaviour */
     void *stream;		/* hipStream_t to run on; NULL = own stream */
 };
 
@@ -101,6 +114,8 @@ struct sora_adsb_counts {	/* of the last scan / resolve */
     uint64_t dirty_squitters;	/* DF11/17/18 with a non-zero syndrome */
     uint64_t replies;		/* candidates of every other DF */
     uint64_t frames;		/* frames sora_adsb_collect will return */
+    uint64_t corrected;		/* dirty squitters taken back by
+				 * SORA_OPT_CORRECT_SINGLE_BIT (not in dirty_squitters) */
 };
 
 typedef struct sora_adsb_ctx sora_adsb_ctx;

@@ -505,6 +505,59 @@ oracle_count_candidates(const float *m, size_t n) {
     return c;
 }
 
+/* ------------------------------------------- D3: single-bit correction -- */
+
+static int g_correction = 0;
+
+void
+oracle_set_correction(int on) {
+    g_correction = on != 0;
+}
+
+int
+oracle_correctable_bit(uint32_t syndrome, int nbits) {
+    /*
+     * Flipping bit b (0 = first) of an nbits-long message adds x^(nbits-1-b)
+     * mod G to crc ^ ap, for data and parity bits alike.  The five DF bits
+     * are never "corrected": that would change the message length and type.
+     */
+    uint32_t v = 1;
+    int k;
+
+    if (syndrome == 0)
+	return -1;
+    for (k = 0; k <= nbits - 6; k++) {
+	if (v == syndrome)
+	    return nbits - 1 - k;
+	v <<= 1;
+	if (v & 0x1000000u)
+	    v ^= 0x1fff409u;
+    }
+    return -1;
+}
+
+/* parse; with correction on, retry a squitter once with the indicated bit
+ * flipped.  bits is modified in place when a correction is made. */
+static int
+parse_with_correction(struct oracle_plane_set *ps, char *bits, long long sec,
+	long long usec, double amplitude, struct oracle_frame *f) {
+    int accepted = oracle_parse_message(ps, bits, sec, usec, amplitude, f);
+
+    f->corrected_bit = -1;
+    if (!accepted && g_correction &&
+	    (f->df == 11 || f->df == 17 || f->df == 18) && f->syndrome != 0) {
+	int b = oracle_correctable_bit(f->syndrome, f->long_message? 112 : 56);
+	if (b >= 0) {
+	    uint32_t before = f->syndrome;
+	    bits[b] ^= '0' ^ '1';
+	    accepted = oracle_parse_message(ps, bits, sec, usec, amplitude, f);
+	    f->syndrome = before;
+	    f->corrected_bit = b;
+	}
+    }
+    return accepted;
+}
+
 size_t
 oracle_scan(const float *m, size_t n, uint64_t base_position,
 	struct oracle_plane_set *ps, int accepted_only,
@@ -530,7 +583,7 @@ oracle_scan(const float *m, size_t n, uint64_t base_position,
 	{
 	    long long sec, usec;
 	    stream_time(f.position, 1700000000ll, 2000000ull, &sec, &usec);
-	    f.accepted = oracle_parse_message(ps, f.bits, sec, usec,
+	    f.accepted = parse_with_correction(ps, f.bits, sec, usec,
 		    f.amplitude, &f);
 	}
 	if (accepted_only && !f.accepted)
@@ -561,8 +614,12 @@ oracle_main_loop(const float *m, size_t n, int flags, long long t0,
 	oracle_slice(m, p, bits, &a56);
 	amplitude = a56 / 56;
 	stream_time(p, t0, rate, &sec, &usec);
-	if (!oracle_parse_message(ps, bits, sec, usec, amplitude, NULL))
-	    continue;					/* :76-77 */
+	{
+	    struct oracle_frame info;
+	    memset(&info, 0, sizeof info);
+	    if (!parse_with_correction(ps, bits, sec, usec, amplitude, &info))
+		continue;				/* :76-77 */
+	}
 	accepted++;
 
 	if (flags & 0x20)				/* :79-82 */

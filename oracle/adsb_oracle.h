@@ -44,6 +44,8 @@ struct oracle_frame {
     uint32_t syndrome;			/* crc ^ ap, plane.c:472-475, :480 */
     uint32_t address;			/* plane.c:474 or :480 */
     int32_t accepted;			/* parse_message returned non-NULL */
+    int32_t corrected_bit;		/* -1, or the bit oracle_set_correction(1)
+					 * made the oracle flip (extension D3) */
 };
 
 /* a1: plane-iq.c:121-139 (uc8); sc8/sc16 by radio-file.c:136-141 scaling.
@@ -77,6 +79,17 @@ size_t oracle_plane_set_count(const struct oracle_plane_set *);
  * validator accepted.  base_position is added to reported positions and used
  * for stream time.
  */
+/*
+ * Extension D3, OFF by default: the reference never
+ * corrects.  When on, a DF11/17/18 candidate whose syndrome equals that of a
+ * single flipped bit b, 5 <= b < 56 (DF11) or 112 (DF17/18), has that bit
+ * flipped back and is parsed again; oracle_frame.syndrome keeps the syndrome
+ * before the flip.  A definition of this build ("parity unpinned").
+ */
+void oracle_set_correction(int on);
+/* the flipped bit a syndrome points at in an nbits-long message, or -1 */
+int oracle_correctable_bit(uint32_t syndrome, int nbits);
+
 size_t oracle_scan(const float *m, size_t n, uint64_t base_position,
 	struct oracle_plane_set *pset, int accepted_only,
 	struct oracle_frame *out, size_t cap);

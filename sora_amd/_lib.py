@@ -21,7 +21,8 @@ BYTES_PER_SAMPLE = {ENC_UC8: 2, ENC_SC8: 2, ENC_SC16: 4}
 ENCODING_NAMES = {"uc8": ENC_UC8, "sc8": ENC_SC8, "sc16": ENC_SC16}
 
 EMIT_ACCEPTED, EMIT_CANDIDATES = 0, 1
-FRAME_LONG, FRAME_SQUITTER, FRAME_ACCEPTED = 1, 2, 4
+FRAME_LONG, FRAME_SQUITTER, FRAME_ACCEPTED, FRAME_CORRECTED = 1, 2, 4, 8
+OPT_CORRECT_SINGLE_BIT = 1
 WINDOW, HALO = 240, 239
 
 
@@ -62,7 +63,7 @@ class Config(C.Structure):
         ("max_squitters", C.c_uint64),
         ("max_frames", C.c_uint64),
         ("emit_mode", C.c_int32),
-        ("reserved", C.c_int32),
+        ("options", C.c_int32),
         ("stream", C.c_void_p),
     ]
 
@@ -70,7 +71,7 @@ class Config(C.Structure):
 class Counts(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in
                 ("positions", "candidates", "squitters", "dirty_squitters",
-                 "replies", "frames")]
+                 "replies", "frames", "corrected")]
 
 
 class SynthFrame(C.Structure):

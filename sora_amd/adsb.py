@@ -62,10 +62,12 @@ class AdsbContext:
     """One device, one stream of samples (struct sora_adsb_ctx)."""
 
     def __init__(self, max_chunk_samples, device=0, emit_mode=EMIT_ACCEPTED,
-                 max_candidates=0, max_squitters=0, max_frames=0, stream=None):
+                 max_candidates=0, max_squitters=0, max_frames=0, stream=None,
+                 correct_single_bit=False):
         self.device = device
+        options = _lib.OPT_CORRECT_SINGLE_BIT if correct_single_bit else 0
         cfg = Config(int(max_chunk_samples), int(max_candidates), int(max_squitters),
-                     int(max_frames), int(emit_mode), 0, stream)
+                     int(max_frames), int(emit_mode), options, stream)
         h = C.c_void_p()
         rc = lib().sora_adsb_create(C.byref(h), device, C.byref(cfg))
         self._h = h.value

@@ -292,6 +292,7 @@ sora_adsb_scan(sora_adsb_ctx *ctx, const void *d_iq, size_t nbytes, int encoding
     a.n_tiles = n_tiles;
     a.encoding = encoding;
     a.emit_all = ctx->cfg.emit_mode == SORA_EMIT_CANDIDATES;
+    a.correct = (ctx->cfg.options & SORA_OPT_CORRECT_SINGLE_BIT) != 0;
     a.rec = ctx->d_rec;
     a.sq = ctx->d_sq;
     a.rec_cap = (uint32_t) (ctx->rec_total / groups > 0x7fffffffull?
@@ -526,6 +527,7 @@ sora_adsb_get_counts(sora_adsb_ctx *ctx, struct sora_adsb_counts *out) {
 	out->squitters += st[SORA_STAT_SQUITTERS];
 	out->dirty_squitters += st[SORA_STAT_DIRTY];
 	out->replies += st[SORA_STAT_REPLIES];
+	out->corrected += st[SORA_STAT_CORRECTED];
     }
     for (uint32_t i = 0; ctx->resolved && i < ctx->res.regions; i++)
 	out->frames += ctx->h_counts[2 * ctx->groups + i];

@@ -15,11 +15,12 @@
 #define SORA_STAT_SQUITTERS	1
 #define SORA_STAT_DIRTY		2
 #define SORA_STAT_REPLIES	3
-#define SORA_STAT_WORDS_BASE	4
+#define SORA_STAT_CORRECTED	4
+#define SORA_STAT_WORDS_BASE	5
 #ifdef SORA_SCAN_STAMPS
-#define SORA_STAT_WORDS		12	/* + 8 phase clocks (diagnostic build) */
+#define SORA_STAT_WORDS		13	/* + 8 phase clocks (diagnostic build) */
 #else
-#define SORA_STAT_WORDS		4
+#define SORA_STAT_WORDS		5
 #endif
 
 struct sora_scan_args {
@@ -29,6 +30,8 @@ struct sora_scan_args {
     uint64_t n_tiles;
     int32_t encoding;
     int32_t emit_all;		/* also record dirty squitters */
+    int32_t correct;		/* SORA_OPT_CORRECT_SINGLE_BIT */
+    int32_t pad_;
     uint64_t *rec;		/* [groups][rec_cap] unified records */
     uint64_t *sq;		/* [groups][sq_cap] clean squitters */
     uint32_t rec_cap, sq_cap;	/* per-group capacities */

@@ -64,15 +64,24 @@ template <> struct tile_geom<true> {		/* sc16: 32-bit magnitudes */
     static constexpr int waves_per_simd = 4;	/* 4 workgroups of 4 waves per CU */
 };
 constexpr int kCrcCopies = SORA_CRC_TABLE_WORDS / 4;	/* 16-byte pieces of the tables */
+constexpr int kFixCopies = SORA_FIX_TABLE_WORDS / 4;	/* ... of the correction lookup */
 
 /* the sliced CRC tables (adsb_tile.h), built at compile time; every tile
  * copies them from L2 into the LDS that M has vacated */
 struct crc_slices {
-    uint32_t w[SORA_CRC_TABLE_WORDS];
+    uint32_t w[SORA_CRC_TABLE_WORDS + SORA_FIX_TABLE_WORDS];
     constexpr crc_slices() : w{} {
 	for (int k = 0; k < SORA_CRC_SLICES; k++)
 	    for (uint32_t v = 0; v < 256; v++)
 		w[k * 256 + v] = sora_crc24_slice_entry(k, v);
+	/* behind them, the single-bit correction lookup (copied only when
+	 * the option is on) */
+	for (int i = 0; i < SORA_FIX_TABLE_WORDS; i++)
+	    w[SORA_CRC_TABLE_WORDS + i] = 0xff000000u;
+	for (int k = 0; k < 112; k++) {
+	    const uint32_t pw = sora_crc_pow(k);
+	    w[SORA_CRC_TABLE_WORDS + sora_fix_hash(pw)] = pw | ((uint32_t) k << 24);
+	}
     }
 };
 __device__ const crc_slices g_crc_slices = crc_slices();
@@ -156,8 +165,8 @@ adsb_scan_kernel(sora_scan_args a) {
     constexpr int kTilePos = G::tile_pos;
     constexpr int kQueueMax = kTilePos / 2;		/* p and p+1 never both hit */
     constexpr int kCrcTableDword = (kQueueMax / 2 + 63) & ~63;	/* past the queue */
-    static_assert(kCrcTableDword + SORA_CRC_TABLE_WORDS <= G::m_dwords,
-	    "CRC tables outside M buffer");
+    static_assert(kCrcTableDword + SORA_CRC_TABLE_WORDS + SORA_FIX_TABLE_WORDS <=
+	    G::m_dwords, "CRC tables outside M buffer");
 
     __shared__ __attribute__((aligned(16))) uint32_t s_m[G::m_dwords];
     /* bit arrays, written as 16-bit halves (one per lane), read as 32-bit words */
@@ -179,7 +188,7 @@ adsb_scan_kernel(sora_scan_args a) {
     uint64_t *rec_out = a.rec + (uint64_t) group * a.rec_cap;
     uint64_t *sq_out = a.sq + (uint64_t) group * a.sq_cap;
     uint32_t n_rec = 0, n_sq = 0;		/* workgroup-uniform */
-    uint32_t st_cand = 0, st_sq = 0, st_dirty = 0;
+    uint32_t st_cand = 0, st_sq = 0, st_dirty = 0, st_fixed = 0;
 
     uint16_t *s_queue = reinterpret_cast<uint16_t *>(s_m);
     uint32_t *s_crc = s_m + kCrcTableDword;
@@ -291,13 +300,14 @@ adsb_scan_kernel(sora_scan_args a) {
 
 	/* ---- phase 3: predicate words, ordered queue of hits ---- */
 	/* the CRC tables for phase 4: fetched now, stored once the scan is done */
-	constexpr int kTabs = (kCrcCopies + kThreads - 1) / kThreads;
+	constexpr int kTabs = (kCrcCopies + kFixCopies + kThreads - 1) / kThreads;
+	const uint32_t copies = a.correct? kCrcCopies + kFixCopies : kCrcCopies;
 	u32x4 tab[kTabs];
 	{
 	    const u32x4 *src = reinterpret_cast<const u32x4 *>(g_crc_slices.w);
 #pragma unroll
 	    for (int c = 0; c < kTabs; c++)
-		if ((c + 1) * kThreads <= kCrcCopies || c * kThreads + tid < kCrcCopies)
+		if ((c + 1) * kThreads <= kCrcCopies || c * kThreads + tid < copies)
 		    tab[c] = src[c * kThreads + tid];
 	}
 	uint32_t pe, po;
@@ -326,7 +336,7 @@ adsb_scan_kernel(sora_scan_args a) {
 	    s_part[wave] = incl;
 #pragma unroll
 	for (int c = 0; c < kTabs; c++)
-	    if ((c + 1) * kThreads <= kCrcCopies || c * kThreads + tid < kCrcCopies)
+	    if ((c + 1) * kThreads <= kCrcCopies || c * kThreads + tid < copies)
 		*reinterpret_cast<u32x4 *>(&s_crc[4 * c * kThreads + 4 * t]) = tab[c];
 	if (tid == 0)
 	    s_sq_count = 0;
@@ -370,14 +380,25 @@ adsb_scan_kernel(sora_scan_args a) {
 
 		sora_extract_bits(words, (q >> 1) + 8, bits);
 		sora_classify(bits, s_crc, &c);
-		const uint64_t kind = !c.squitter? SORA_REC_KIND_REPLY :
+		uint64_t kind = !c.squitter? SORA_REC_KIND_REPLY :
 			c.syndrome == 0? SORA_REC_KIND_SQUITTER : SORA_REC_KIND_DIRTY;
-		const uint64_t record = sora_rec_make(kind, tile_start + q,
-			kind == SORA_REC_KIND_DIRTY? c.syndrome : c.address);
+		uint32_t payload = kind == SORA_REC_KIND_DIRTY? c.syndrome : c.address;
+		if (a.correct && kind == SORA_REC_KIND_DIRTY) {
+		    /* option: a syndrome that one flipped bit explains */
+		    const int b = sora_fix_bit(c.syndrome, c.is_long? 112 : 56,
+			    s_crc + SORA_CRC_TABLE_WORDS);
+		    if (b >= 0) {
+			kind = SORA_REC_KIND_CORRECTED;
+			payload = c.address;		/* bits[8,32) */
+			if (b >= 8 && b < 32)
+			    payload ^= 1u << (31 - b);
+		    }
+		}
+		const uint64_t record = sora_rec_make(kind, tile_start + q, payload);
 		const uint32_t idx = n_rec + i;
 		if (idx < a.rec_cap)
 		    rec_out[idx] = record;
-		if (kind == SORA_REC_KIND_SQUITTER) {
+		if (kind == SORA_REC_KIND_SQUITTER || kind == SORA_REC_KIND_CORRECTED) {
 		    const uint32_t k = n_sq + atomicAdd(&s_sq_count, 1u);
 		    if (k < a.sq_cap)
 			sq_out[k] = record;
@@ -385,6 +406,8 @@ adsb_scan_kernel(sora_scan_args a) {
 		/* wave-uniform counts: ballots land in SGPRs, off the VALU */
 		st_sq += (uint32_t) __popcll(__ballot(kind == SORA_REC_KIND_SQUITTER));
 		st_dirty += (uint32_t) __popcll(__ballot(kind == SORA_REC_KIND_DIRTY));
+		if (a.correct)
+		    st_fixed += (uint32_t) __popcll(__ballot(kind == SORA_REC_KIND_CORRECTED));
 	    }
 	}
 	n_rec += total;
@@ -403,23 +426,26 @@ adsb_scan_kernel(sora_scan_args a) {
     }
     /* statistics: st_cand is workgroup-uniform, the others wave-uniform */
     {
-	__shared__ uint32_t s_stat[kWaves][2];
+	__shared__ uint32_t s_stat[kWaves][3];
 	if (lane == 0) {
 	    s_stat[wave][0] = st_sq;
 	    s_stat[wave][1] = st_dirty;
+	    s_stat[wave][2] = st_fixed;
 	}
 	__syncthreads();
 	if (tid == 0) {
-	    uint64_t t1 = 0, t2 = 0;
+	    uint64_t t1 = 0, t2 = 0, t3 = 0;
 	    for (int w = 0; w < kWaves; w++) {
 		t1 += s_stat[w][0];
 		t2 += s_stat[w][1];
+		t3 += s_stat[w][2];
 	    }
 	    uint64_t *st = a.stats + (uint64_t) group * SORA_STAT_WORDS;
 	    st[SORA_STAT_CANDIDATES] = st_cand;
 	    st[SORA_STAT_SQUITTERS] = t1;
 	    st[SORA_STAT_DIRTY] = t2;
-	    st[SORA_STAT_REPLIES] = st_cand - t1 - t2;
+	    st[SORA_STAT_REPLIES] = st_cand - t1 - t2 - t3;
+	    st[SORA_STAT_CORRECTED] = t3;
 #ifdef SORA_SCAN_STAMPS
 	    for (int i = 0; i < 8; i++)
 		st[SORA_STAT_WORDS_BASE + i] = st_t[i];
@@ -586,7 +612,7 @@ filter_kernel(sora_resolve_args a) {
 	    const uint32_t kind = sora_rec_kind(r[u]);
 	    keep[u] = false;
 	    if (i < end) {
-		if (kind == SORA_REC_KIND_SQUITTER) {
+		if (kind == SORA_REC_KIND_SQUITTER || kind == SORA_REC_KIND_CORRECTED) {
 		    keep[u] = true;
 		    r[u] |= SORA_REC_ACCEPTED << 60;
 		} else if (kind == SORA_REC_KIND_REPLY) {
@@ -723,6 +749,23 @@ finalize_one(const sora_resolve_args &a, uint64_t f, uint64_t r, const frame_mag
     const uint32_t syndrome = x ^ ap;
     const bool squitter = df == 11 || df == 17 || df == 18;
 
+    /* option: the scan marked this squitter as one flipped bit away from a
+     * clean one; find the bit (syndrome == x^k mod G, b = n - 1 - k) and flip
+     * it back */
+    int corrected = -1;
+    if ((sora_rec_kind(r) & 3) == SORA_REC_KIND_CORRECTED) {
+	const int nbits = is_long? 112 : 56;
+	const unsigned long long k_lo = __ballot(c_crc_pow.r[lane] == syndrome);
+	const unsigned long long k_hi = __ballot(lane < 48 &&
+		c_crc_pow.r[64 + (lane < 48? lane : 0)] == syndrome);
+	const int k = k_lo != 0? __builtin_ctzll(k_lo) :
+		k_hi != 0? 64 + __builtin_ctzll(k_hi) : -1;
+	if (k >= 0 && k <= nbits - 6) {
+	    corrected = nbits - 1 - k;
+	    bits[corrected >> 5] ^= 0x80000000u >> (corrected & 31);
+	}
+    }
+
     /* plane-iq.c:62-73: float (s0+s1)/2 accumulated in double, in order */
     if (lane < 56)
 	s_amp[lane] = __fmul_rn(__fadd_rn(m.a0, m.a1), 0.5f);
@@ -753,9 +796,10 @@ finalize_one(const sora_resolve_args &a, uint64_t f, uint64_t r, const frame_mag
 	fr.address = squitter? (bits[0] & 0xffffffu) : syndrome;
 	fr.sum56 = sum56;
 	fr.df = (uint8_t) df;
-	fr.corrected_bit = -1;
+	fr.corrected_bit = (int8_t) corrected;
 	fr.flags = (uint8_t) ((is_long? SORA_FRAME_LONG : 0) |
 		(squitter? SORA_FRAME_SQUITTER : 0) |
+		(corrected >= 0? SORA_FRAME_CORRECTED : 0) |
 		((sora_rec_kind(r) & SORA_REC_ACCEPTED)? SORA_FRAME_ACCEPTED : 0));
 	fr.reserved = 0;
 	a.frames[f] = fr;

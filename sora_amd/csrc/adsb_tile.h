@@ -68,6 +68,7 @@
 #define SORA_REC_KIND_REPLY	0ull	/* DF other than 11/17/18 */
 #define SORA_REC_KIND_SQUITTER	1ull	/* DF 11/17/18, syndrome 0 */
 #define SORA_REC_KIND_DIRTY	2ull	/* DF 11/17/18, syndrome != 0 */
+#define SORA_REC_KIND_CORRECTED	3ull	/* DF 11/17/18, single-bit syndrome, option on */
 #define SORA_REC_ACCEPTED	4ull	/* or-ed into kind by the filter */
 #define SORA_REC_POS_BITS	36
 
@@ -424,6 +425,58 @@ sora_crc24_slice_entry(int k, uint32_t byte) {
 	    r ^= 0x1fff409u;
     }
     return r & 0xffffffu;
+}
+
+/*
+ * Single-bit correction (option).  Flipping bit b of
+ * an n-bit message adds x^(n-1-b) mod G to the syndrome, so the correctable
+ * syndromes are POW[k] = x^k mod G, k = 0..111 (k <= n - 6: the DF bits are
+ * left alone).  Lookup: a 512-entry table addressed by a multiplicative hash
+ * that is perfect on those 112 values (multiplier found by search, checked at
+ * compile time); an entry holds POW[k] | k << 24, empty entries hold 0xff << 24.
+ */
+#define SORA_FIX_TABLE_WORDS	512
+#define SORA_FIX_MULT		0xc60d7f03u
+
+SORA_HD constexpr uint32_t
+sora_crc_pow(int k) {
+    uint32_t v = 1;
+    for (int i = 0; i < k; i++) {
+	v <<= 1;
+	if (v & 0x1000000u)
+	    v ^= 0x1fff409u;
+    }
+    return v;
+}
+
+SORA_HD constexpr uint32_t
+sora_fix_hash(uint32_t syndrome) {
+    return (syndrome * SORA_FIX_MULT) >> 23;
+}
+
+SORA_HD constexpr bool
+sora_fix_hash_is_perfect() {
+    bool used[SORA_FIX_TABLE_WORDS] = {};
+    for (int k = 0; k < 112; k++) {
+	const uint32_t h = sora_fix_hash(sora_crc_pow(k));
+	if (used[h])
+	    return false;
+	used[h] = true;
+    }
+    return true;
+}
+static_assert(sora_fix_hash_is_perfect(), "SORA_FIX_MULT collides");
+
+/* bit to flip in an nbits-long message with this syndrome, or -1.
+ * table: SORA_FIX_TABLE_WORDS words as described above */
+SORA_HD int
+sora_fix_bit(uint32_t syndrome, int nbits, const uint32_t *table) {
+    const uint32_t e = table[sora_fix_hash(syndrome)];
+    const int k = (int) (e >> 24);
+
+    if ((e & 0xffffffu) != syndrome || k > nbits - 6)
+	return -1;
+    return nbits - 1 - k;
 }
 
 struct sora_candidate {

@@ -98,6 +98,9 @@ plane_iq_state_new_encoded(FILE *f, int encoding) {
 	cfg.emit_mode = SORA_EMIT_CANDIDATES;
 	cfg.max_candidates = cfg.max_chunk_samples / 2 + 1024;
     }
+    /* opt-in extension: off, as in the reference */
+    if ((s = getenv("SORA_ADSB_CORRECT")) != NULL && atoi(s) != 0)
+	cfg.options |= SORA_OPT_CORRECT_SINGLE_BIT;
     /* a block cannot hold more accepted frames than one per 2 positions */
     cfg.max_squitters = cfg.max_chunk_samples / 64 + 65536;
     s = getenv("SORA_ADSB_DEVICE");

@@ -70,12 +70,14 @@ def frames_as_dicts(frames):
                         amplitude=float(f["amplitude_56"]) / 56,
                         df=int(f["df"]), syndrome=int(f["syndrome"]),
                         address=int(f["address"]),
-                        accepted=bool(int(f["flags"]) & FRAME_ACCEPTED)))
+                        accepted=bool(int(f["flags"]) & FRAME_ACCEPTED),
+                        corrected_bit=int(f["corrected_bit"])))
     return out
 
 
 def assert_same_frames(got, want, fields=("position", "bits", "amplitude_56", "amplitude",
-                                          "df", "syndrome", "address", "accepted")):
+                                          "df", "syndrome", "address", "accepted",
+                                          "corrected_bit")):
     assert len(got) == len(want), f"{len(got)} frames, expected {len(want)}"
     for i, (g, w) in enumerate(zip(got, want)):
         for k in fields:

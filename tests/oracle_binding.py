@@ -27,6 +27,7 @@ class OracleFrame(C.Structure):
         ("syndrome", C.c_uint32),
         ("address", C.c_uint32),
         ("accepted", C.c_int32),
+        ("corrected_bit", C.c_int32),
     ]
 
 
@@ -63,6 +64,9 @@ def lib():
                                            C.c_longlong, C.c_double, C.c_void_p]
         L.oracle_print_last.restype = C.c_int
         L.oracle_print_last.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+        L.oracle_set_correction.argtypes = [C.c_int]
+        L.oracle_correctable_bit.restype = C.c_int
+        L.oracle_correctable_bit.argtypes = [C.c_uint32, C.c_int]
         _lib = L
     return _lib
 
@@ -102,15 +106,20 @@ class PlaneSet:
 
 
 def scan(iq_bytes, encoding=ENC_UC8, accepted_only=False, base_position=0,
-         plane_set=None, cap=None):
-    """The whole chain on a capture: list of frame dicts in stream order."""
+         plane_set=None, cap=None, correct=False):
+    """The whole chain on a capture: list of frame dicts in stream order.
+    correct=True turns on the single-bit correction extension (D3)."""
     m = magnitude(iq_bytes, encoding)
     ps = plane_set or PlaneSet()
     if cap is None:
         cap = max(1024, m.size // 2 + 16)
     arr = (OracleFrame * cap)()
-    n = lib().oracle_scan(m.ctypes.data, m.size, base_position, ps.h,
-                          1 if accepted_only else 0, arr, cap)
+    lib().oracle_set_correction(1 if correct else 0)
+    try:
+        n = lib().oracle_scan(m.ctypes.data, m.size, base_position, ps.h,
+                              1 if accepted_only else 0, arr, cap)
+    finally:
+        lib().oracle_set_correction(0)
     assert n <= cap, "oracle frame buffer too small"
     out = []
     for i in range(n):
@@ -118,11 +127,13 @@ def scan(iq_bytes, encoding=ENC_UC8, accepted_only=False, base_position=0,
         out.append(dict(position=f.position, bits=f.bits.decode(),
                         amplitude_56=f.amplitude_56, amplitude=f.amplitude,
                         df=f.df, long=f.long_message, syndrome=f.syndrome,
-                        address=f.address, accepted=bool(f.accepted)))
+                        address=f.address, accepted=bool(f.accepted),
+                        corrected_bit=f.corrected_bit))
     return out
 
 
-def main_loop_text(iq_bytes, flags, encoding=ENC_UC8, t0=1700000000, rate=2000000):
+def main_loop_text(iq_bytes, flags, encoding=ENC_UC8, t0=1700000000, rate=2000000,
+                   correct=False):
     """planes_main_loop output of the oracle, as text (TZ from environment)."""
     import tempfile
     L = lib()
@@ -138,7 +149,9 @@ def main_loop_text(iq_bytes, flags, encoding=ENC_UC8, t0=1700000000, rate=200000
         path = tf.name
     try:
         fp = libc.fopen(path.encode(), b"w")
+        L.oracle_set_correction(1 if correct else 0)
         L.oracle_main_loop(m.ctypes.data, m.size, flags, t0, rate, fp)
+        L.oracle_set_correction(0)
         libc.fclose(fp)
         with open(path) as fh:
             return fh.read()

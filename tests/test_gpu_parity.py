@@ -317,3 +317,60 @@ def test_sc16_frames_on_tile_edges():
     got, _ = gpu_frames(raw, ENC_SC16)
     assert_same_frames(got, want)
     assert set(edges) <= {c["position"] for c in got if c["accepted"]}
+
+
+# ---- single-bit correction, opt-in; parity unpinned:
+# the reference never corrects, the oracle restates this build's definition.
+
+def test_correction_off_by_default_and_on():
+    p = synth.default_params(4, n_samples=1500000, seed=9)      # 20 % flipped-bit frames
+    p.encoding = ENC_UC8
+    p.amp_min, p.amp_max = 30, 110
+    raw = synth.fill_host(p.n_samples, p.encoding, p.seed, synth.make_frames(p)).tobytes()
+    plain = ob.scan(raw)
+    fixed = ob.scan(raw, correct=True)
+    n_fixed = sum(1 for c in fixed if c["corrected_bit"] >= 0)
+    assert n_fixed > 100 and all(c["corrected_bit"] < 0 for c in plain)
+    got, counts = gpu_frames(raw)                               # option off
+    assert_same_frames(got, plain)
+    assert counts["corrected"] == 0
+    n = len(raw) // 2
+    with AdsbContext(n, emit_mode=EMIT_CANDIDATES, max_candidates=n // 2,
+                     max_squitters=n // 2, correct_single_bit=True) as ctx:
+        ctx.submit_host(raw, ENC_UC8)
+        got = frames_as_dicts(ctx.collect())
+        counts = ctx.counts()
+    assert_same_frames(got, fixed)
+    assert counts["corrected"] == n_fixed
+    with AdsbContext(n, max_squitters=n // 2, correct_single_bit=True) as ctx:
+        ctx.submit_host(raw, ENC_UC8)
+        acc = frames_as_dicts(ctx.collect())
+    assert_same_frames(acc, [c for c in fixed if c["accepted"]])
+
+
+def test_correction_sc16_every_bit():
+    """One clean DF17 and one DF11 per flipped bit position: 5..111 and 5..55."""
+    klm = synth.hex_to_bits("8D4840D6202CC371C32CE0576098")
+    df11 = synth.hex_to_bits("5D4840D6F8740F")
+    rows, pos = [], 400
+    for b in range(112):
+        w = np.array(klm, dtype=np.uint32).copy()
+        w[b >> 5] ^= np.uint32(0x80000000 >> (b & 31))
+        rows.append((pos, w, 9000, 0, 112))
+        pos += 300
+    for b in range(56):
+        w = np.array(df11, dtype=np.uint32).copy()
+        w[b >> 5] ^= np.uint32(0x80000000 >> (b & 31))
+        rows.append((pos, w, 9000, 0, 56))
+        pos += 300
+    raw = synth.fill_host(pos + 600, ENC_SC16, 3, synth.frame_table(rows)).tobytes()
+    want = ob.scan(raw, ENC_SC16, correct=True)
+    fixed_bits = sorted(c["corrected_bit"] for c in want if c["corrected_bit"] >= 0
+                        and c["position"] >= 400 and (c["position"] - 400) % 300 == 0)
+    assert fixed_bits == sorted(list(range(5, 112)) + list(range(5, 56)))
+    n = len(raw) // 4
+    with AdsbContext(n, emit_mode=EMIT_CANDIDATES, max_candidates=n // 2,
+                     max_squitters=n // 2, correct_single_bit=True) as ctx:
+        ctx.submit_host(raw, ENC_SC16)
+        got = frames_as_dicts(ctx.collect())
+    assert_same_frames(got, want)

@@ -93,3 +93,35 @@ def test_oracle_matches_reference_live(seed):
     env = {"TZ": "UTC", "SORA_T0": "1700000000", "SORA_RATE": "2000000"}
     assert ob.main_loop_text(iq, 0x10) == ob.ref_main_loop(iq, False, True, env)
     assert ob.main_loop_text(iq, 0x20) == ob.ref_main_loop(iq, True, True, env)
+
+
+def test_correction_extension_is_off_by_default_and_round_trips():
+    """Extension D3, parity unpinned: every single
+    flipped bit b >= 5 of a clean DF17 / DF11 is found again; DF bits are not."""
+    from sora_amd import synth
+    L = ob.lib()
+    for hexmsg, nbits in (("8D4840D6202CC371C32CE0576098", 112), ("5D4840D6F8740F", 56)):
+        clean = "".join(format(w, "032b") for w in synth.hex_to_bits(hexmsg))[:112]
+        ps = ob.PlaneSet()
+        ok, f = ps.parse(clean)
+        assert ok and f.syndrome == 0
+        for b in range(nbits):
+            flipped = clean[:b] + ("1" if clean[b] == "0" else "0") + clean[b + 1:]
+            ok, f = ob.PlaneSet().parse(flipped)
+            if b < 5:
+                continue                      # another DF: not a squitter any more
+            assert not ok
+            assert L.oracle_correctable_bit(f.syndrome, nbits) == b
+    assert L.oracle_correctable_bit(0, 112) == -1
+    assert L.oracle_correctable_bit(0x123456, 112) == -1
+    # x^107 mod G is the syndrome of bit 4 of a long message: inside the DF field
+    v = 1
+    for _ in range(107):
+        v <<= 1
+        if v & 0x1000000:
+            v ^= 0x1FFF409
+    assert L.oracle_correctable_bit(v, 112) == -1
+    # scan(): default output is unchanged by the existence of the extension
+    rng = np.random.default_rng(3)
+    raw = rng.integers(0, 256, size=2 * 50000, dtype=np.uint8).tobytes()
+    assert all(c["corrected_bit"] == -1 for c in ob.scan(raw))
