@@ -37,6 +37,7 @@ extern "C" {
 #endif
 
 #define SORA_OK			0
+#define SORA_END		1	/* sora_adsb_stream_next: the stream is over */
 #define SORA_ERR_INVALID	(-1)	/* bad argument */
 #define SORA_ERR_NO_DEVICE	(-2)	/* no usable gfx950 device */
 #define SORA_ERR_HIP		(-3)	/* a HIP call failed: sora_adsb_last_error() */
@@ -170,6 +171,30 @@ int sora_adsb_submit_device(sora_adsb_ctx *ctx, const void *d_iq, size_t nbytes,
 /* same from host memory: staged through the context's device buffer */
 int sora_adsb_submit_host(sora_adsb_ctx *ctx, const void *h_iq, size_t nbytes,
 	int encoding, uint64_t base_position, uint64_t n_owned);
+
+/*
+ * Streaming ingest: captures larger than HBM, files,
+ * live stdin.  No counterpart in the reference, whose iterator pulls single
+ * samples through a 4096-float ring (plane-iq.c:141-166).  The library reads
+ * blocks of block_samples through `read`, carries the last 239 samples of a
+ * block in front of the next (a candidate at p reads p .. p+239), and double
+ * buffers: while block k is scanned and resolved on the context's stream,
+ * block k+1 is read into pinned memory and copied to the device on a second
+ * stream.  Known addresses persist across blocks (plane.c:90-105).
+ *
+ * read(user, dst, nbytes) stores up to nbytes bytes and returns the count,
+ * fewer than asked only at the end of the stream (fread semantics).
+ * stream_next hands out the frames of one block, in position order, in memory
+ * that stays valid until the next stream_next / stream_end; it returns SORA_END
+ * (with *n = 0) once the last block has been handed out.
+ * Needs block_samples + 239 <= max_chunk_samples and block_samples >= 1024.
+ */
+typedef size_t (*sora_adsb_read_fn)(void *user, void *dst, size_t nbytes);
+int sora_adsb_stream_begin(sora_adsb_ctx *ctx, int encoding, uint64_t block_samples,
+	sora_adsb_read_fn read, void *user);
+int sora_adsb_stream_next(sora_adsb_ctx *ctx, const struct sora_adsb_frame **frames,
+	size_t *n);
+int sora_adsb_stream_end(sora_adsb_ctx *ctx);
 
 /*
  * Waits for the stream, then copies the frames of the last resolve, in

@@ -110,6 +110,9 @@ class SynthParams(C.Structure):
     ]
 
 
+READ_FN = C.CFUNCTYPE(C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t)
+END = 1
+
 # every symbol include/sora_adsb_gpu.h and include/sora_synth.h declare
 _SIGNATURES = {
     "sora_adsb_version": (C.c_char_p, []),
@@ -129,6 +132,11 @@ _SIGNATURES = {
                                           C.c_uint64, C.c_uint64]),
     "sora_adsb_submit_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int,
                                         C.c_uint64, C.c_uint64]),
+    "sora_adsb_stream_begin": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64, READ_FN,
+                                         C.c_void_p]),
+    "sora_adsb_stream_next": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p),
+                                        C.POINTER(C.c_size_t)]),
+    "sora_adsb_stream_end": (C.c_int, [C.c_void_p]),
     "sora_adsb_collect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t,
                                     C.POINTER(C.c_size_t)]),
     "sora_adsb_collect_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t,

@@ -132,6 +132,41 @@ class AdsbContext:
                                           base_position, n_owned), self._h)
 
     # -- results ----------------------------------------------------------
+    def stream(self, source, encoding, block_samples):
+        """Streaming ingest (sora_adsb_stream_*): `source` is a bytes-like object
+        or a binary file object; yields one FRAME_DTYPE array per block."""
+        if hasattr(source, "readinto"):
+            def read(_user, dst, nbytes):
+                buf = (C.c_char * nbytes).from_address(dst)
+                return source.readinto(buf) or 0
+        else:
+            view = memoryview(source).cast("B")
+            at = [0]
+
+            def read(_user, dst, nbytes):
+                k = min(nbytes, len(view) - at[0])
+                if k > 0:
+                    C.memmove(dst, (C.c_char * k).from_buffer_copy(view[at[0]:at[0] + k]), k)
+                at[0] += k
+                return k
+        cb = _lib.READ_FN(read)
+        check(lib().sora_adsb_stream_begin(self._h, int(encoding), int(block_samples),
+                                           cb, None), self._h)
+        try:
+            while True:
+                ptr, n = C.c_void_p(), C.c_size_t()
+                rc = lib().sora_adsb_stream_next(self._h, C.byref(ptr), C.byref(n))
+                if rc == _lib.END:
+                    break
+                check(rc, self._h)
+                if n.value:
+                    raw = C.string_at(ptr.value, n.value * FRAME_DTYPE.itemsize)
+                    yield np.frombuffer(raw, dtype=FRAME_DTYPE).copy()
+                else:
+                    yield np.empty(0, dtype=FRAME_DTYPE)
+        finally:
+            lib().sora_adsb_stream_end(self._h)
+
     def collect(self, cap=None):
         """Frames of the last resolve as a numpy structured array (FRAME_DTYPE)."""
         n = C.c_size_t()

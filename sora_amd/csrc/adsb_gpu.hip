@@ -49,6 +49,25 @@ struct sora_adsb_ctx {
     sora_resolve_args res;
     uint32_t groups;
 
+    /* streaming ingest (sora_adsb_stream_*) */
+    struct {
+	bool active, done;
+	int encoding, bps;
+	uint64_t block;
+	sora_adsb_read_fn read;
+	void *user;
+	uint8_t *h_in[2], *d_in[2];
+	sora_adsb_frame *h_out[2];
+	hipStream_t copy;
+	hipEvent_t ev_in[2];	/* block is on the device */
+	hipEvent_t ev_free[2];	/* the kernels are done with d_in[slot] */
+	uint64_t n_samples[2], base[2], n_owned[2];
+	bool filled[2], last[2];
+	uint64_t consumed;	/* samples taken from the source */
+	uint64_t carry;		/* samples the next block starts with */
+	int cur;
+    } st;
+
     char err[256];
 };
 
@@ -64,6 +83,8 @@ fail(sora_adsb_ctx *ctx, int code, const char *fmt, ...) {
     }
     return code;
 }
+
+void stream_release(sora_adsb_ctx *ctx);
 
 #define HIP_TRY(ctx, call) do { \
 	hipError_t e_ = (call); \
@@ -131,6 +152,10 @@ sora_adsb_destroy(sora_adsb_ctx *ctx) {
     (void) hipSetDevice(ctx->device);
     if (ctx->stream != nullptr)
 	(void) hipStreamSynchronize(ctx->stream);
+    if (ctx->st.active) {
+	(void) hipStreamSynchronize(ctx->st.copy);
+	stream_release(ctx);
+    }
     (void) hipFree(ctx->d_rec);
     (void) hipFree(ctx->d_sq);
     (void) hipFree(ctx->d_acc);
@@ -532,6 +557,175 @@ sora_adsb_get_counts(sora_adsb_ctx *ctx, struct sora_adsb_counts *out) {
     for (uint32_t i = 0; ctx->resolved && i < ctx->res.regions; i++)
 	out->frames += ctx->h_counts[2 * ctx->groups + i];
     return overflow? SORA_ERR_OVERFLOW : SORA_OK;
+}
+
+/* ---- streaming ingest ---- */
+
+namespace {
+
+void
+stream_release(sora_adsb_ctx *ctx) {
+    auto &s = ctx->st;
+    for (int i = 0; i < 2; i++) {
+	if (s.h_in[i] != nullptr)
+	    (void) hipHostFree(s.h_in[i]);
+	if (s.h_out[i] != nullptr)
+	    (void) hipHostFree(s.h_out[i]);
+	if (s.d_in[i] != nullptr)
+	    (void) hipFree(s.d_in[i]);
+	if (s.ev_in[i] != nullptr)
+	    (void) hipEventDestroy(s.ev_in[i]);
+	if (s.ev_free[i] != nullptr)
+	    (void) hipEventDestroy(s.ev_free[i]);
+    }
+    if (s.copy != nullptr)
+	(void) hipStreamDestroy(s.copy);
+    memset(&s, 0, sizeof s);
+}
+
+/* reads the next block into slot (behind the carried tail of the other slot)
+ * and starts its copy to the device */
+int
+stream_fill(sora_adsb_ctx *ctx, int slot) {
+    auto &s = ctx->st;
+    const size_t bps = (size_t) s.bps;
+    const int prev = slot ^ 1;
+
+    /* the pinned buffer may still be the source of its last copy */
+    HIP_TRY(ctx, hipEventSynchronize(s.ev_in[slot]));
+    if (s.carry > 0)
+	memcpy(s.h_in[slot], s.h_in[prev] + (s.n_samples[prev] - s.carry) * bps,
+		s.carry * bps);
+    const size_t want = (size_t) s.block * bps;
+    uint8_t *dst = s.h_in[slot] + s.carry * bps;
+    size_t got = 0;
+    while (got < want) {
+	const size_t k = s.read(s.user, dst + got, want - got);
+	if (k == 0 || k > want - got)
+	    break;
+	got += k;
+    }
+    /* whole samples only: a trailing partial sample is dropped
+     * (plane-iq.c:131, :138; radio-file.c:122) */
+    const uint64_t fresh = got / bps;
+    s.last[slot] = got < want;
+    s.n_samples[slot] = s.carry + fresh;
+    s.base[slot] = s.consumed - s.carry;
+    s.n_owned[slot] = s.last[slot]? s.n_samples[slot] :
+	    s.n_samples[slot] - SORA_ADSB_HALO;
+    s.consumed += fresh;
+    s.carry = s.last[slot]? 0 : SORA_ADSB_HALO;
+    s.filled[slot] = true;
+
+    HIP_TRY(ctx, hipStreamWaitEvent(s.copy, s.ev_free[slot], 0));
+    if (s.n_samples[slot] > 0)
+	HIP_TRY(ctx, hipMemcpyAsync(s.d_in[slot], s.h_in[slot],
+		(size_t) s.n_samples[slot] * bps, hipMemcpyHostToDevice, s.copy));
+    HIP_TRY(ctx, hipEventRecord(s.ev_in[slot], s.copy));
+    return SORA_OK;
+}
+
+} /* namespace */
+
+extern "C" int
+sora_adsb_stream_begin(sora_adsb_ctx *ctx, int encoding, uint64_t block_samples,
+	sora_adsb_read_fn read, void *user) {
+    if (ctx == nullptr)
+	return SORA_ERR_INVALID;
+    const int bps = bytes_per_sample(encoding);
+    if (bps == 0 || read == nullptr)
+	return fail(ctx, SORA_ERR_INVALID, "bad stream arguments");
+    if (block_samples < 1024 ||
+	    block_samples + SORA_ADSB_HALO > ctx->cfg.max_chunk_samples)
+	return fail(ctx, SORA_ERR_INVALID, "block of %llu samples: need >= 1024 and "
+		"block + 239 <= max_chunk_samples (%llu)",
+		(unsigned long long) block_samples,
+		(unsigned long long) ctx->cfg.max_chunk_samples);
+    if (ctx->st.active)
+	return fail(ctx, SORA_ERR_STATE, "a stream is already open");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+
+    auto &s = ctx->st;
+    memset(&s, 0, sizeof s);
+    s.encoding = encoding;
+    s.bps = bps;
+    s.block = block_samples;
+    s.read = read;
+    s.user = user;
+    const size_t in_bytes = (size_t) (block_samples + SORA_ADSB_HALO) * (size_t) bps + 16;
+    const size_t out_bytes = (size_t) (ctx->frames_cap > 0? ctx->frames_cap : 1) *
+	    sizeof(sora_adsb_frame);
+    bool ok = hipStreamCreateWithFlags(&s.copy, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; ok && i < 2; i++) {
+	ok = hipHostMalloc(reinterpret_cast<void **>(&s.h_in[i]), in_bytes,
+			hipHostMallocDefault) == hipSuccess &&
+		hipHostMalloc(reinterpret_cast<void **>(&s.h_out[i]), out_bytes,
+			hipHostMallocDefault) == hipSuccess &&
+		hipMalloc(reinterpret_cast<void **>(&s.d_in[i]), in_bytes) == hipSuccess &&
+		hipEventCreateWithFlags(&s.ev_in[i], hipEventDisableTiming) == hipSuccess &&
+		hipEventCreateWithFlags(&s.ev_free[i], hipEventDisableTiming) == hipSuccess;
+    }
+    if (!ok) {
+	stream_release(ctx);
+	return fail(ctx, SORA_ERR_NOMEM, "stream buffers (2 x %zu bytes pinned and "
+		"device, 2 x %zu bytes of frames)", in_bytes, out_bytes);
+    }
+    s.active = true;
+    return SORA_OK;
+}
+
+extern "C" int
+sora_adsb_stream_next(sora_adsb_ctx *ctx, const sora_adsb_frame **frames, size_t *n) {
+    if (ctx == nullptr || frames == nullptr || n == nullptr)
+	return SORA_ERR_INVALID;
+    *frames = nullptr;
+    *n = 0;
+    auto &s = ctx->st;
+    if (!s.active)
+	return fail(ctx, SORA_ERR_STATE, "no stream is open");
+    if (s.done)
+	return SORA_END;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+
+    const int cur = s.cur;
+    int rc;
+    if (!s.filled[cur] && (rc = stream_fill(ctx, cur)) != SORA_OK)
+	return rc;
+    /* this block: scan + resolve behind its copy */
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, s.ev_in[cur], 0));
+    rc = sora_adsb_submit_device(ctx, s.d_in[cur],
+	    (size_t) s.n_samples[cur] * (size_t) s.bps, s.encoding, s.base[cur],
+	    s.n_owned[cur]);
+    if (rc != SORA_OK)
+	return rc;
+    HIP_TRY(ctx, hipEventRecord(s.ev_free[cur], ctx->stream));
+    /* the next block: read and copied while the kernels run */
+    if (!s.last[cur] && (rc = stream_fill(ctx, cur ^ 1)) != SORA_OK)
+	return rc;
+    size_t got = 0;
+    rc = sora_adsb_collect(ctx, s.h_out[cur], (size_t) ctx->frames_cap, &got);
+    if (rc != SORA_OK)
+	return rc;
+    *frames = s.h_out[cur];
+    *n = got;
+    s.filled[cur] = false;
+    if (s.last[cur])
+	s.done = true;
+    s.cur = cur ^ 1;
+    return SORA_OK;
+}
+
+extern "C" int
+sora_adsb_stream_end(sora_adsb_ctx *ctx) {
+    if (ctx == nullptr)
+	return SORA_ERR_INVALID;
+    if (!ctx->st.active)
+	return SORA_OK;
+    (void) hipSetDevice(ctx->device);
+    (void) hipStreamSynchronize(ctx->st.copy);
+    (void) hipStreamSynchronize(ctx->stream);
+    stream_release(ctx);
+    return SORA_OK;
 }
 
 #ifdef SORA_SCAN_STAMPS

@@ -3,11 +3,13 @@
  * src/ads-b/plane-iq.h:10-13 on top of the gfx950 library.
  *
  * The reference pulls one sample at a time through a 4096-float ring
- * (plane-iq.c:141-194).  Here the stream is read in blocks of tens of
- * millions of samples, every block is handed to the device together with the
- * last 239 samples of the previous one (a candidate at p reads p .. p+239),
- * and the frames the device returns are yielded one per call, in position
- * order -- the order in which the reference completes them (plane-iq.c:76-83).
+ * (plane-iq.c:141-194).  Here the library's streaming ingest
+ * (sora_adsb_stream_*) reads the FILE in blocks of tens of millions of
+ * samples into pinned memory, double buffered against the kernels, every
+ * block together with the last 239 samples of the previous one (a candidate
+ * at p reads p .. p+239); the frames the device returns are yielded one per
+ * call, in position order -- the order in which the reference completes them
+ * (plane-iq.c:76-83).
  *
  * Time: the reference stamps a candidate with gettimeofday() when it meets
  * the preamble (plane-iq.c:46), i.e. with the time at which it happened to
@@ -30,14 +32,11 @@ struct plane_iq_state {
     int bytes_per_sample;
     sora_adsb_ctx *ctx;
 
-    unsigned char *buf;		/* tail of the previous block + this block */
     size_t block_samples;
-    size_t tail_samples;	/* samples carried over, <= 239 */
-    unsigned long long next_position;	/* stream index of buf[0] */
     int eof;
 
-    struct sora_adsb_frame *frames;
-    size_t frames_cap, n_frames, next_frame;
+    const struct sora_adsb_frame *frames;	/* of the current block: library memory */
+    size_t n_frames, next_frame;
 
     long long t0;
     unsigned long long rate;
@@ -57,6 +56,12 @@ encoding_bytes(int encoding) {
     default:
 	return 0;
     }
+}
+
+/* sora_adsb_read_fn over a FILE: fread semantics */
+static size_t
+read_file(void *user, void *dst, size_t nbytes) {
+    return fread(dst, 1, nbytes, (FILE *) user);
 }
 
 struct plane_iq_state *
@@ -113,12 +118,10 @@ plane_iq_state_new_encoded(FILE *f, int encoding) {
 	return NULL;
     }
 
-    st->buf = malloc((st->block_samples + SORA_ADSB_HALO) * (size_t) st->bytes_per_sample);
-    st->frames_cap = cfg.emit_mode == SORA_EMIT_CANDIDATES?
-	    (size_t) cfg.max_candidates : (size_t) cfg.max_squitters;
-    st->frames = malloc(st->frames_cap * sizeof *st->frames);
-    if (st->buf == NULL || st->frames == NULL) {
-	fprintf(stderr, "sora: out of memory\n");
+    rc = sora_adsb_stream_begin(st->ctx, encoding, st->block_samples, read_file, f);
+    if (rc != SORA_OK) {
+	fprintf(stderr, "sora: cannot open the GPU ADS-B stream: %s (%s)\n",
+		sora_adsb_strerror(rc), sora_adsb_last_error(st->ctx));
 	plane_iq_state_delete(st);
 	return NULL;
     }
@@ -134,36 +137,25 @@ void
 plane_iq_state_delete(struct plane_iq_state *st) {
     if (st == NULL)
 	return;
+    (void) sora_adsb_stream_end(st->ctx);
     sora_adsb_destroy(st->ctx);
-    free(st->buf);
-    free(st->frames);
     free(st);			/* the FILE stays open, like plane-iq.c:114-119 */
 }
 
-/* reads the next block, runs it on the device; 0 when the stream is over */
+/* the frames of the next block; 0 when the stream is over */
 static int
 next_block(struct plane_iq_state *st) {
-    const size_t bps = (size_t) st->bytes_per_sample;
-    size_t got, n_samples, n_owned;
     int rc;
 
     if (st->eof)
 	return 0;
-    /* whole samples only; a trailing partial sample is dropped
-     * (plane-iq.c:131, :138; radio-file.c:122) */
-    got = fread(st->buf + st->tail_samples * bps, bps, st->block_samples, st->f);
-    if (got < st->block_samples)
+    rc = sora_adsb_stream_next(st->ctx, &st->frames, &st->n_frames);
+    st->next_frame = 0;
+    if (rc == SORA_END) {
 	st->eof = 1;
-    n_samples = st->tail_samples + got;
-    /* every position whose 240-sample window is complete; at the end of the
-     * stream the device drops p + 240 > n itself (plane-iq.c:148-166) */
-    n_owned = st->eof? n_samples :
-	    (n_samples >= SORA_ADSB_HALO? n_samples - SORA_ADSB_HALO : 0);
-
-    rc = sora_adsb_submit_host(st->ctx, st->buf, n_samples * bps, st->encoding,
-	    st->next_position, n_owned);
-    if (rc == SORA_OK)
-	rc = sora_adsb_collect(st->ctx, st->frames, st->frames_cap, &st->n_frames);
+	st->n_frames = 0;
+	return 0;
+    }
     if (rc != SORA_OK) {
 	fprintf(stderr, "sora: GPU ADS-B path failed: %s (%s)\n",
 		sora_adsb_strerror(rc), sora_adsb_last_error(st->ctx));
@@ -171,17 +163,6 @@ next_block(struct plane_iq_state *st) {
 	st->eof = 1;
 	st->n_frames = 0;
 	return 0;
-    }
-    if (st->n_frames > st->frames_cap)
-	st->n_frames = st->frames_cap;
-    st->next_frame = 0;
-
-    if (!st->eof) {
-	/* carry the unowned tail */
-	const size_t keep = n_samples - n_owned;
-	memmove(st->buf, st->buf + n_owned * bps, keep * bps);
-	st->tail_samples = keep;
-	st->next_position += n_owned;
     }
     return 1;
 }

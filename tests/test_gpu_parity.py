@@ -374,3 +374,40 @@ def test_correction_sc16_every_bit():
         ctx.submit_host(raw, ENC_SC16)
         got = frames_as_dicts(ctx.collect())
     assert_same_frames(got, want)
+
+
+# ---- streaming ingest: sora_adsb_stream_*
+
+@pytest.mark.parametrize("enc,block", [(ENC_UC8, 1024), (ENC_UC8, 50000), (ENC_UC8, 400000),
+                                       (ENC_SC16, 30000)])
+def test_stream_blocks_equal_whole(enc, block):
+    """Blocks through pinned double buffers with a 239-sample carry give the
+    frames of the whole capture; a block boundary that is also the end of the
+    stream and a trailing partial sample are covered by the sizes."""
+    p = synth.default_params(4 if enc == ENC_SC16 else 2, n_samples=400000, mean_gap=700,
+                             reply_permille=250, unknown_permille=200, n_icao=5, seed=31)
+    p.encoding = enc
+    raw = synth.fill_host(p.n_samples, enc, p.seed, synth.make_frames(p)).tobytes() + b"\x07"
+    want = [c for c in ob.scan(raw, enc) if c["accepted"]]
+    assert len(want) > 50
+    n = 400000
+    with AdsbContext(block + 239, max_squitters=block + 1024) as ctx:
+        parts = list(ctx.stream(raw, enc, block))
+    assert len(parts) == n // block + 1
+    got = frames_as_dicts(np.concatenate(parts))
+    assert_same_frames(got, want)
+
+
+def test_stream_empty_and_errors():
+    with AdsbContext(100000) as ctx:
+        assert [len(x) for x in ctx.stream(b"", ENC_UC8, 4096)] == [0]
+        with pytest.raises(sora_amd.SoraError):
+            list(ctx.stream(b"", ENC_UC8, 100))            # block too small
+        with pytest.raises(sora_amd.SoraError):
+            list(ctx.stream(b"", ENC_UC8, 100000))         # block + 239 > max_chunk
+        # a file object as the source
+        import io
+        rng = np.random.default_rng(2)
+        raw = rng.integers(0, 256, size=2 * 30000, dtype=np.uint8).tobytes()
+        got = frames_as_dicts(np.concatenate(list(ctx.stream(io.BytesIO(raw), ENC_UC8, 8192))))
+        assert_same_frames(got, [c for c in ob.scan(raw) if c["accepted"]])
