@@ -411,3 +411,34 @@ def test_stream_empty_and_errors():
         raw = rng.integers(0, 256, size=2 * 30000, dtype=np.uint8).tobytes()
         got = frames_as_dicts(np.concatenate(list(ctx.stream(io.BytesIO(raw), ENC_UC8, 8192))))
         assert_same_frames(got, [c for c in ob.scan(raw) if c["accepted"]])
+
+
+def test_config5_batched_archive():
+    """BASELINE configs[4] in small: independent recordings (uc8 and sc8) through
+    one context, sora_adsb_reset() between them; plane sets must not leak."""
+    recs = []
+    for i in range(6):
+        enc = ENC_UC8 if i % 2 == 0 else ENC_SC8
+        p = synth.default_params(1, n_samples=250000, mean_gap=900, reply_permille=300,
+                                 unknown_permille=0, n_icao=4, seed=500 + i)
+        p.encoding = enc
+        recs.append((enc, synth.fill_host(p.n_samples, enc, p.seed,
+                                          synth.make_frames(p)).tobytes()))
+    with AdsbContext(250000, max_squitters=100000) as ctx:
+        for enc, raw in recs:
+            ctx.reset()
+            ctx.submit_host(raw, enc)
+            got = frames_as_dicts(ctx.collect())
+            assert_same_frames(got, [c for c in ob.scan(raw, enc) if c["accepted"]])
+        # without the reset the planes of the previous recording stay known
+        # (plane.c:90-105 never expires them): more replies are accepted
+        enc, raw = recs[0]
+        ctx.reset()
+        ctx.submit_host(recs[2][1], recs[2][0])
+        ctx.collect()
+        ctx.submit_host(raw, enc)
+        leaked = ctx.collect()
+        ps = ob.PlaneSet()
+        ob.scan(recs[2][1], recs[2][0], plane_set=ps)
+        want = [c for c in ob.scan(raw, enc, plane_set=ps) if c["accepted"]]
+        assert_same_frames(frames_as_dicts(leaked), want)
