@@ -4,7 +4,10 @@
 A step is one pass of the hot path over one synthetic capture that is already
 resident in HBM: scan kernel -> (N>1: squitter-record exchange over RCCL) ->
 first-seen merge, reply filter, re-slice of the accepted frames -> frame list
-in host memory (N>1: gathered to rank 0 over RCCL first).  At N=1 the workload
+in host memory (N>1: every rank copies its frames over its own PCIe link into
+a host segment the node's ranks share; rank 0 reads the whole list there).
+Two captures are in flight (--inflight): the scan of one overlaps the resolve
+and the host copy of the one before.  At N=1 the workload
 is BASELINE.json configs[1]: a 1-hour 2 MS/s uc8 capture (7.2 G samples,
 14.4 GB) with DF17/DF11 at mixed SNR.  For N>1 every rank holds one such
 1-hour shard of an N-hour capture (weak scaling), 239 halo samples behind it.
@@ -43,6 +46,12 @@ def parse_args():
     ap.add_argument("--encoding", choices=("uc8", "sc8", "sc16"), default="uc8",
                     help="uc8 is BASELINE.json's metric; sc8/sc16 are side measurements "
                          "(sc16 uses the dense configs[3] traffic)")
+    ap.add_argument("--inflight", type=int, default=2,
+                    help="captures in flight (decoders on streams of their own); 1 = "
+                         "strictly one after the other")
+    ap.add_argument("--gather", choices=("shm", "collective"), default="shm",
+                    help="N>1: frame lists to rank 0 through a shared host segment "
+                         "(every rank over its own PCIe link) or by an RCCL gather")
     ap.add_argument("--force-collective", action="store_true",
                     help="run the N>1 exchange code path even with one rank (rehearsal)")
     return ap.parse_args()
@@ -93,7 +102,7 @@ def main():
     import sora_amd
     from sora_amd import FRAME_DTYPE, AdsbContext, synth
     from sora_amd._lib import BYTES_PER_SAMPLE as BPS, ENCODING_NAMES
-    from sora_amd.sharded import ShardedDecoder
+    from sora_amd.sharded import LocalDecoder, ShardedDecoder
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -131,29 +140,66 @@ def main():
     torch.cuda.synchronize()
 
     max_frames = per_gpu // (64 if args.encoding == "sc16" else 1024) + 65536
-    ctx = AdsbContext(n_local, device=local, max_squitters=max_frames,
-                      max_frames=max_frames)             # ~3x the injected frame rate
     collective = world > 1 or args.force_collective
-    if collective:
-        # scan -> squitter-record all-gather -> resolve -> frame-list gather
-        sharded = ShardedDecoder(ctx, rank, world, dev, max_frames)
-        h_frames = sharded.h_frames
-    else:
-        h_pin = torch.empty(max_frames * FRAME_DTYPE.itemsize, dtype=torch.uint8,
-                            pin_memory=True)
-        h_frames = h_pin.numpy().view(FRAME_DTYPE)
-
-    scan_ms = []
-
-    def step():
+    # `inflight` decoders, each a context on a stream of its own: while one
+    # capture's frames are resolved and copied to the host, the next capture's
+    # scan already runs (two captures in flight is double buffering, the way an
+    # archive of recordings is worked through).  Every step still does all of
+    # its work inside the timed region.
+    streams, ctxs, decs = [], [], []
+    for _ in range(max(1, args.inflight)):
+        st = torch.cuda.Stream(device=dev)
+        ctx = AdsbContext(n_local, device=local, max_squitters=max_frames,
+                          max_frames=max_frames, stream=st.cuda_stream)
+        streams.append(st)                           # ~3x the injected frame rate
+        ctxs.append(ctx)
         if collective:
-            n = sharded.step(d_iq, bps * n_local, enc, first, per_gpu)
+            # scan -> squitter-record all-gather (RCCL) -> resolve -> every rank
+            # copies its frames to its offset in a host segment shared by the node
+            decs.append(ShardedDecoder(ctx, rank, world, dev, max_frames, stream=st,
+                                       gather=args.gather))
         else:
-            ctx.reset()                                      # a new capture: no known planes
-            ctx.submit_device(d_iq, bps * n_local, enc, base_position=first,
-                              n_owned=per_gpu)
-            n = ctx.collect_into(h_frames)                   # frame list in host memory
-        scan_ms.append(ctx.last_scan_ms())
+            decs.append(LocalDecoder(ctx, max_frames))
+    ctx = ctxs[0]
+    job = (d_iq, bps * n_local, enc, first, per_gpu)
+
+    scan_ms = []                       # HIP-event duration of every scan kernel launch
+
+    phase_s = {"begin": 0.0, "finish": 0.0, "exchange": 0.0}
+
+    def timed(name, fn, *a):
+        t = time.perf_counter()
+        r = fn(*a)
+        phase_s[name] += time.perf_counter() - t
+        return r
+
+    def finish(d):
+        n = timed("finish", d.finish)      # frames of that capture are on the host
+        scan_ms.append(d.ctx.last_scan_ms())
+        return n
+
+    def run(k):
+        """k steps, pipelined over the decoders; returns the last frame count."""
+        n, prev, resolved = 0, None, None
+        for i in range(k):
+            d = decs[i % len(decs)]
+            if len(decs) == 1 and prev is not None:
+                n, prev = finish(prev), None
+            if resolved is not None:
+                # kernels of the two captures run one after the other (a scan that
+                # shares the CUs with another capture's resolve gets stragglers);
+                # what overlaps this scan is the previous capture's copy to the host
+                streams[i % len(decs)].wait_event(resolved)
+            timed("begin", d.begin, *job)  # reset (a new capture) + scan, asynchronous
+            if prev is not None:
+                n = finish(prev)
+            timed("exchange", d.exchange)  # (N>1: squitter exchange) + resolve
+            if len(decs) > 1:
+                resolved = torch.cuda.Event()
+                resolved.record(streams[i % len(decs)])
+            prev = d
+        if prev is not None:
+            n = finish(prev)
         return n
 
     def fence():
@@ -162,13 +208,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        n_frames = step()
-    scan_ms.clear()
+    n_frames = run(args.warmup)
     fence()
+    scan_ms.clear()
+    for k in phase_s:
+        phase_s[k] = 0.0
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        n_frames = step()
+    n_frames = run(args.steps)
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -207,6 +253,8 @@ def main():
             "samples_per_gpu": per_gpu, "bytes_per_gpu": bps * n_local,
             "injected_frames": int(len(frames)), "frames_out": int(n_frames),
             "candidates_rank0": int(counts["candidates"]),
+            "captures_in_flight": len(decs),
+            "host_ms_per_step": {k: round(v / args.steps * 1e3, 3) for k, v in phase_s.items()},
         },
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
@@ -220,7 +268,7 @@ def main():
     if (rank == 0 and world == 1 and not args.no_cpu and args.cpu_samples > 0
             and args.encoding == "uc8"):          # the reference reads uc8 only
         n_cpu = min(int(args.cpu_samples), per_gpu)
-        pos = h_frames["position"][:n_frames]
+        pos = decs[(args.steps - 1) % len(decs)].frames()["position"]
         in_window = int(np.count_nonzero(pos < n_cpu - 239))
         line["cpu_baseline"] = cpu_baseline(d_iq, n_cpu, in_window)
     else:
@@ -228,7 +276,10 @@ def main():
 
     if rank == 0:
         print(json.dumps(line), flush=True)
-    ctx.close()
+    for d in decs:
+        d.close()
+    for c in ctxs:
+        c.close()
     if dist.is_initialized():
         dist.destroy_process_group()
 

@@ -229,6 +229,14 @@ int sora_adsb_copy_to_device(int device, void *d_dst, const void *h_src,
 	size_t nbytes);
 int sora_adsb_copy_to_host(int device, void *h_dst, const void *d_src,
 	size_t nbytes);
+/*
+ * Page-locks host memory the caller owns (for example a shared-memory segment
+ * that several per-GPU processes write their frame lists into) so that
+ * sora_adsb_collect() copies into it by DMA at full PCIe rate.  No counterpart
+ * in the reference.
+ */
+int sora_adsb_host_register(int device, void *h_ptr, size_t nbytes);
+int sora_adsb_host_unregister(int device, void *h_ptr);
 
 #ifdef __cplusplus
 }

@@ -150,6 +150,8 @@ _SIGNATURES = {
     "sora_adsb_device_free": (C.c_int, [C.c_int, C.c_void_p]),
     "sora_adsb_copy_to_device": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]),
     "sora_adsb_copy_to_host": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "sora_adsb_host_register": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t]),
+    "sora_adsb_host_unregister": (C.c_int, [C.c_int, C.c_void_p]),
     "sora_synth_default_params": (C.c_int, [C.c_int, C.POINTER(SynthParams)]),
     "sora_synth_make_frames": (C.c_size_t, [C.POINTER(SynthParams), C.c_void_p,
                                             C.c_size_t]),

@@ -186,6 +186,13 @@ class AdsbContext:
               self._h)
         return n.value
 
+    def frame_count(self):
+        """Frames the last resolve produced (waits for it)."""
+        c = self.counts()
+        if c["overflow"]:
+            raise _lib.SoraError(_lib.ERR_OVERFLOW, "a device list overflowed")
+        return int(c["frames"])
+
     def collect_device(self, d_out, cap):
         n = C.c_size_t()
         check(lib().sora_adsb_collect_device(self._h, _ptr(d_out), cap, C.byref(n)),

@@ -820,3 +820,24 @@ sora_adsb_copy_to_host(int device, void *h_dst, const void *d_src, size_t nbytes
     return hipMemcpy(h_dst, d_src, nbytes, hipMemcpyDeviceToHost) == hipSuccess?
 	    SORA_OK : SORA_ERR_HIP;
 }
+
+extern "C" int
+sora_adsb_host_register(int device, void *h_ptr, size_t nbytes) {
+    if (h_ptr == nullptr || nbytes == 0)
+	return SORA_ERR_INVALID;
+    if (hipSetDevice(device) != hipSuccess)
+	return SORA_ERR_NO_DEVICE;
+    if (hipHostRegister(h_ptr, nbytes, hipHostRegisterDefault) == hipSuccess)
+	return SORA_OK;
+    (void) hipGetLastError();	/* not sticky: the caller may go on without */
+    return SORA_ERR_HIP;
+}
+
+extern "C" int
+sora_adsb_host_unregister(int device, void *h_ptr) {
+    if (h_ptr == nullptr)
+	return SORA_ERR_INVALID;
+    if (hipSetDevice(device) != hipSuccess)
+	return SORA_ERR_NO_DEVICE;
+    return hipHostUnregister(h_ptr) == hipSuccess? SORA_OK : SORA_ERR_HIP;
+}

@@ -867,10 +867,12 @@ sora_launch_scan(const sora_scan_args *a, uint32_t groups, hipStream_t stream) {
     switch (a->encoding) {
     case SORA_ENC_UC8:
     case SORA_ENC_SC8:
+	(void) hipGetLastError();
 	hipLaunchKernelGGL(adsb_scan_kernel<false>, dim3(groups),
 		dim3(tile_geom<false>::threads), 0, stream, *a);
 	break;
     case SORA_ENC_SC16:
+	(void) hipGetLastError();
 	hipLaunchKernelGGL(adsb_scan_kernel<true>, dim3(groups),
 		dim3(tile_geom<true>::threads), 0, stream, *a);
 	break;
@@ -883,6 +885,7 @@ sora_launch_scan(const sora_scan_args *a, uint32_t groups, hipStream_t stream) {
 hipError_t
 sora_launch_fill_u64(uint64_t *dst, uint64_t value, uint64_t n,
 	hipStream_t stream) {
+    (void) hipGetLastError();
     hipLaunchKernelGGL(fill_u64_kernel, dim3(grid_for(n, 1024)), dim3(256), 0,
 	    stream, dst, value, n);
     return hipGetLastError();
@@ -890,6 +893,7 @@ sora_launch_fill_u64(uint64_t *dst, uint64_t value, uint64_t n,
 
 hipError_t
 sora_launch_first_seen(const sora_resolve_args *a, hipStream_t stream) {
+    (void) hipGetLastError();
     hipLaunchKernelGGL(first_seen_kernel, dim3(a->groups), dim3(kSmall), 0,
 	    stream, *a);
     return hipGetLastError();
@@ -900,6 +904,7 @@ sora_launch_add_known(uint64_t *first_seen, uint32_t *known_bits,
 	const uint64_t *records, uint64_t n, hipStream_t stream) {
     if (n == 0)
 	return hipSuccess;
+    (void) hipGetLastError();
     hipLaunchKernelGGL(add_known_kernel, dim3(grid_for(n, 256)), dim3(256), 0,
 	    stream, first_seen, known_bits, records, n);
     return hipGetLastError();
@@ -908,6 +913,7 @@ sora_launch_add_known(uint64_t *first_seen, uint32_t *known_bits,
 hipError_t
 sora_launch_scan_counts(const uint32_t *counts, uint32_t cap,
 	uint64_t *offsets, uint32_t n, hipStream_t stream) {
+    (void) hipGetLastError();
     hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream,
 	    counts, cap, offsets, n);
     return hipGetLastError();
@@ -920,6 +926,7 @@ sora_launch_export_squitters(const sora_resolve_args *a, uint64_t *scan_tmp,
 	    a->groups, stream);
     if (e != hipSuccess)
 	return e;
+    (void) hipGetLastError();
     hipLaunchKernelGGL(export_squitters_kernel, dim3(a->groups), dim3(256), 0,
 	    stream, *a, scan_tmp, dst, dst_cap);
     return hipGetLastError();
@@ -927,6 +934,7 @@ sora_launch_export_squitters(const sora_resolve_args *a, uint64_t *scan_tmp,
 
 hipError_t
 sora_launch_filter(const sora_resolve_args *a, hipStream_t stream) {
+    (void) hipGetLastError();
     hipLaunchKernelGGL(filter_kernel, dim3(a->groups), dim3(kSmall), 0, stream,
 	    *a);
     return hipGetLastError();
@@ -939,6 +947,7 @@ sora_filter_regions(uint32_t groups) {
 
 hipError_t
 sora_launch_finalize(const sora_resolve_args *a, uint32_t cus, hipStream_t stream) {
+    (void) hipGetLastError();
     hipLaunchKernelGGL(flatten_kernel, dim3(a->regions), dim3(kSmall), 0, stream,
 	    *a);
     hipError_t e = hipGetLastError();
@@ -946,6 +955,7 @@ sora_launch_finalize(const sora_resolve_args *a, uint32_t cus, hipStream_t strea
 	return e;
     /* 8 blocks of 4 waves per CU: every wave slot busy hiding the two
      * dependent fetches (record, then samples) of a frame */
+    (void) hipGetLastError();
     hipLaunchKernelGGL(finalize_kernel, dim3(cus * 8), dim3(kSmall), 0, stream, *a);
     return hipGetLastError();
 }
@@ -955,6 +965,7 @@ sora_launch_magnitude(const uint8_t *iq, uint64_t n_samples, int encoding,
 	float *m, hipStream_t stream) {
     if (n_samples == 0)
 	return hipSuccess;
+    (void) hipGetLastError();
     hipLaunchKernelGGL(magnitude_kernel, dim3(grid_for(n_samples, 256)),
 	    dim3(256), 0, stream, iq, n_samples, encoding, m);
     return hipGetLastError();

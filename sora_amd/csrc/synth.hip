@@ -448,6 +448,7 @@ sora_synth_fill_device(void *dst, uint64_t first, uint64_t count, int encoding,
     }
     uint64_t nblocks = (count + kFillBlock - 1) / kFillBlock;
     uint32_t grid = nblocks > 16384? 16384u : (uint32_t) nblocks;
+    (void) hipGetLastError();
     hipLaunchKernelGGL(synth_fill_kernel, dim3(grid), dim3(kFillThreads), 0, st,
 	    (uint8_t *) dst, first, count, encoding, seed, d_frames,
 	    (uint64_t) nframes);

@@ -4,11 +4,31 @@ One process per GPU; rank r owns the positions [r*per, (r+1)*per) of the
 capture and holds 239 halo samples behind them.  The scan needs no
 communication.  The path's one exchange: every rank's clean-squitter records
 (position << 24 | address, 8 bytes each) are all-gathered so that each rank's
-first-seen table knows the addresses earlier ranks introduced; the compacted
-frame lists are then gathered to rank 0, whose concatenation in rank order is
-the position order.  `torch.distributed` carries both (backend nccl = RCCL
-over xGMI on the GPUs, gloo in the CPU tests); sample data never moves.
+first-seen table knows the addresses earlier ranks introduced
+(`torch.distributed`: backend nccl = RCCL over xGMI on the GPUs, gloo in the
+CPU tests).  Sample data never moves.
+
+The frame lists go to the host, not to another GPU: the ranks of one node
+share a host-memory segment (/dev/shm) with one slot per rank, and every rank
+copies its frames over ITS OWN PCIe link into its slot (by DMA if the segment
+can be page-locked, else through a pinned buffer of the rank and a CPU copy
+that is pipelined with the DMA).  Counts and completion travel through a small
+header of the same segment, so this phase issues no device collective: one
+would queue behind the other capture's scan kernel, whose persistent
+workgroups leave no room on the CUs until it ends.  The slots in rank order
+are the position order; rank 0 reads the whole list there without a byte of
+it crossing xGMI or queueing on one PCIe link.  `gather="collective"` keeps
+the plain RCCL gather to rank 0 (ranks on several nodes).
+
+A step is three phases so that two decoders (two contexts, two streams) can be
+interleaved: begin() launches the scan, exchange() waits for its squitter
+count, exchanges the records and launches the resolve, finish() waits for the
+frames and places them.  step() runs the three in a row.
 """
+import contextlib
+import os
+import time
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -16,6 +36,8 @@ import torch.distributed as dist
 from ._lib import BYTES_PER_SAMPLE, FRAME_DTYPE, HALO
 
 FRAME_BYTES = FRAME_DTYPE.itemsize
+HEADER_WORDS = 8                    # u64 per rank: seq, n_frames, ack (rank 0), pad
+SPIN_TIMEOUT_S = 300.0
 
 
 def plan_shards(total_samples, world):
@@ -32,55 +54,217 @@ def plan_shards(total_samples, world):
     return out
 
 
-class ShardedDecoder:
-    """Drives one context per rank through scan -> exchange -> resolve -> gather."""
+class LocalDecoder:
+    """The same three phases on one GPU with no exchange at all."""
 
-    def __init__(self, ctx, rank, world, device, max_frames, group=None):
+    def __init__(self, ctx, max_frames, pin=True):
+        self.ctx = ctx
+        self.h_pin = torch.empty(int(max_frames) * FRAME_BYTES, dtype=torch.uint8,
+                                 pin_memory=pin)
+        self.h_frames = self.h_pin.numpy().view(FRAME_DTYPE)
+        self.n = 0
+
+    def begin(self, d_iq, nbytes, encoding, base_position, n_owned, reset=True):
+        if reset:
+            self.ctx.reset()
+        self.ctx.scan(d_iq, nbytes, encoding, base_position=base_position,
+                      n_owned=n_owned)
+
+    def exchange(self):
+        self.ctx.resolve()
+
+    def finish(self):
+        self.n = self.ctx.collect_into(self.h_frames)
+        return self.n
+
+    def frames(self):
+        return self.h_frames[:self.n]
+
+    def step(self, *args, **kw):
+        self.begin(*args, **kw)
+        self.exchange()
+        return self.finish()
+
+    def close(self):
+        pass
+
+
+class ShardedDecoder:
+    """Drives one context per rank through scan -> exchange -> resolve -> gather.
+
+    `stream`: the torch.cuda.Stream the context was created on (AdsbContext(...,
+    stream=s.cuda_stream)); collectives and context launches are then ordered by
+    that one stream.  None: the context must be on torch's current stream, or be
+    a CPU stand-in."""
+
+    def __init__(self, ctx, rank, world, device, max_frames, group=None, stream=None,
+                 gather="shm"):
         self.ctx, self.rank, self.world = ctx, rank, world
         self.device, self.max_frames, self.group = device, int(max_frames), group
+        self.stream, self.gather = stream, gather
+        self.cuda = device.type == "cuda"
         self.d_sq = torch.zeros(self.max_frames, dtype=torch.int64, device=device)
         self.d_sq_all = torch.zeros(world * self.max_frames, dtype=torch.int64,
                                     device=device)
+        self.counts = torch.zeros(world, dtype=torch.int64, device=device)
         self.d_out = torch.zeros(self.max_frames * FRAME_BYTES, dtype=torch.uint8,
                                  device=device)
-        self.d_gather = ([torch.zeros_like(self.d_out) for _ in range(world)]
-                         if rank == 0 else None)
-        self.counts = torch.zeros(world, dtype=torch.int64, device=device)
-        pin = device.type == "cuda"
-        n_host = self.max_frames * (world if rank == 0 else 1)
-        self.h_pin = torch.empty(n_host * FRAME_BYTES, dtype=torch.uint8, pin_memory=pin)
-        self.h_frames = self.h_pin.numpy().view(FRAME_DTYPE)
+        self.seq = 0
+        self.ns = [0] * world
+        self._registered = None
+        self._mm = None
+        if gather == "shm":
+            self._open_segment()
+        else:
+            self.d_gather = ([torch.zeros_like(self.d_out) for _ in range(world)]
+                             if rank == 0 else None)
+            n_host = self.max_frames * (world if rank == 0 else 1)
+            self.h_pin = torch.empty(n_host * FRAME_BYTES, dtype=torch.uint8,
+                                     pin_memory=self.cuda)
+            self.h_frames = self.h_pin.numpy().view(FRAME_DTYPE)
+
+    # -- the shared host segment -------------------------------------------
+    def _open_segment(self):
+        self.slot_bytes = max(1, self.max_frames) * FRAME_BYTES
+        self.slot_bytes += -self.slot_bytes % 4096
+        self.data_at = 4096                      # the header has a page of its own
+        nbytes = self.data_at + self.world * self.slot_bytes
+        nbytes += -nbytes % (2 << 20)
+        name = [None]
+        if self.rank == 0:
+            name[0] = f"/dev/shm/sora_frames_{os.getpid()}_{id(self):x}"
+            with open(name[0], "wb") as fh:
+                fh.truncate(nbytes)              # zero filled: seq = ack = 0
+        dist.broadcast_object_list(name, src=0, group=self.group)
+        self._mm = np.memmap(name[0], dtype=np.uint8, mode="r+", shape=(nbytes,))
+        dist.barrier(group=self.group)           # every rank has it mapped
+        if self.rank == 0:
+            os.unlink(name[0])                   # the mappings keep it alive
+        self.header = self._mm[:self.world * HEADER_WORDS * 8].view(np.uint64).reshape(
+            self.world, HEADER_WORDS)
+        self.slots = [self._mm[self.data_at + r * self.slot_bytes:
+                               self.data_at + r * self.slot_bytes +
+                               self.max_frames * FRAME_BYTES].view(FRAME_DTYPE)
+                      for r in range(self.world)]
+        if self.cuda:
+            from . import _lib
+            idx = self.device.index if self.device.index is not None else 0
+            rc = _lib.lib().sora_adsb_host_register(idx, self._mm.ctypes.data, nbytes)
+            if rc == _lib.OK:
+                self._registered = (idx, self._mm.ctypes.data)
+        if self._registered is None:
+            # the segment cannot be page-locked here (RLIMIT_MEMLOCK, containers):
+            # DMA into a pinned buffer of this rank, then a CPU copy into the slot
+            self.h_stage_t = torch.empty(self.max_frames * FRAME_BYTES, dtype=torch.uint8,
+                                         pin_memory=self.cuda)
+            base = self.data_at + self.rank * self.slot_bytes
+            self.h_slot_t = torch.from_numpy(self._mm)[base:base + self.slot_bytes]
+
+    def close(self):
+        if self._registered is not None:
+            from . import _lib
+            _lib.lib().sora_adsb_host_unregister(*self._registered)
+            self._registered = None
+        self.header = self.slots = self.h_slot_t = None
+        self._mm = None
+
+    def _on_stream(self):
+        if self.stream is not None:
+            return torch.cuda.stream(self.stream)
+        return contextlib.nullcontext()
 
     def _all_counts(self, k):
         mine = torch.tensor([k], dtype=torch.int64, device=self.device)
         dist.all_gather_into_tensor(self.counts, mine, group=self.group)
         return [int(x) for x in self.counts.tolist()]
 
-    def step(self, d_iq, nbytes, encoding, base_position, n_owned, reset=True):
-        """One pass over this rank's shard.  Returns the total number of frames
-        (all ranks); on rank 0, self.h_frames[:n] holds them in position order."""
-        ctx, world, rank = self.ctx, self.world, self.rank
+    def _spin(self, ready, what):
+        t0 = time.monotonic()
+        while not ready():
+            if time.monotonic() - t0 > SPIN_TIMEOUT_S:
+                raise RuntimeError(f"rank {self.rank}: timed out waiting for {what}")
+            time.sleep(0)
+
+    # -- the three phases ---------------------------------------------------
+    def begin(self, d_iq, nbytes, encoding, base_position, n_owned, reset=True):
+        if self.gather == "shm" and self.rank == 0:
+            # the reader lets go of the previous result of this decoder
+            self.header[0, 2] = self.seq
+        self.seq += 1
         if reset:
-            ctx.reset()
-        ctx.scan(d_iq, nbytes, encoding, base_position=base_position, n_owned=n_owned)
+            self.ctx.reset()
+        self.ctx.scan(d_iq, nbytes, encoding, base_position=base_position,
+                      n_owned=n_owned)
 
-        ks = self._all_counts(ctx.squitter_count())
-        if max(ks) > self.max_frames:
-            raise RuntimeError(f"{max(ks)} squitter records exceed max_frames")
-        m = max(ks)
-        if m:
-            ctx.copy_squitters(self.d_sq, self.max_frames)
-            ctx.synchronize()
-            dist.all_gather_into_tensor(self.d_sq_all[:world * m], self.d_sq[:m],
-                                        group=self.group)
-            for r in range(world):
-                if r != rank and ks[r]:
-                    ctx.add_known(self.d_sq_all[r * m:r * m + ks[r]], ks[r])
-        ctx.resolve()
+    def exchange(self):
+        ctx, world, rank = self.ctx, self.world, self.rank
+        with self._on_stream():
+            ks = self._all_counts(ctx.squitter_count())
+            if max(ks) > self.max_frames:
+                raise RuntimeError(f"{max(ks)} squitter records exceed max_frames")
+            m = max(ks)
+            if m:
+                ctx.copy_squitters(self.d_sq, self.max_frames)
+                ctx.synchronize()
+                dist.all_gather_into_tensor(self.d_sq_all[:world * m], self.d_sq[:m],
+                                            group=self.group)
+                if self.cuda and self.stream is None:
+                    torch.cuda.current_stream().synchronize()
+                for r in range(world):
+                    if r != rank and ks[r]:
+                        ctx.add_known(self.d_sq_all[r * m:r * m + ks[r]], ks[r])
+            ctx.resolve()
 
+    def finish(self):
+        """Total number of frames (all ranks); on rank 0, frames() returns them in
+        position order (valid until this decoder's next begin())."""
+        with self._on_stream():
+            if self.gather == "shm":
+                return self._finish_shm()
+            return self._finish_collective()
+
+    def _finish_shm(self):
+        ctx, r = self.ctx, self.rank
+        # rank 0 has let go of what this slot held (two steps ago)
+        self._spin(lambda: int(self.header[0, 2]) >= self.seq - 1, "the reader's release")
+        if self._registered is not None:
+            n = ctx.frame_count()
+            if n > self.max_frames:
+                raise RuntimeError(f"{n} frames exceed max_frames")
+            if n:
+                assert ctx.collect_into(self.slots[r][:n]) == n      # DMA into the slot
+        else:
+            # DMA into this rank's pinned buffer in pieces, each piece copied into
+            # the slot by the CPU while the next one is on the link
+            n = ctx.collect_device(self.d_out, self.max_frames)
+            if n > self.max_frames:
+                raise RuntimeError(f"{n} frames exceed max_frames")
+            total = n * FRAME_BYTES
+            cuts = list(range(0, total, 16 << 20)) + [total]
+            events = []
+            for a, b in zip(cuts, cuts[1:]):
+                self.h_stage_t[a:b].copy_(self.d_out[a:b], non_blocking=True)
+                if self.cuda:
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    events.append(ev)
+            for i, (a, b) in enumerate(zip(cuts, cuts[1:])):
+                if self.cuda:
+                    events[i].synchronize()
+                self.h_slot_t[a:b].copy_(self.h_stage_t[a:b])
+        # publish: count first, then the sequence number the others wait for
+        self.header[r, 1] = n
+        self.header[r, 0] = self.seq
+        self._spin(lambda: bool((self.header[:, 0] >= self.seq).all()), "the other ranks")
+        self.ns = [int(x) for x in self.header[:, 1]]
+        return sum(self.ns)
+
+    def _finish_collective(self):
+        ctx, world, rank = self.ctx, self.world, self.rank
         ns = self._all_counts(ctx.collect_device(self.d_out, self.max_frames))
         if max(ns) > self.max_frames:
             raise RuntimeError(f"{max(ns)} frames exceed max_frames")
+        self.ns = ns
         m = max(ns) * FRAME_BYTES
         if m:
             dist.gather(self.d_out[:m],
@@ -92,6 +276,21 @@ class ShardedDecoder:
                 nb = ns[r] * FRAME_BYTES
                 self.h_pin[off:off + nb].copy_(self.d_gather[r][:nb], non_blocking=True)
                 off += nb
-            if self.device.type == "cuda":
-                torch.cuda.synchronize()
+            if self.cuda:
+                torch.cuda.current_stream().synchronize()
         return sum(ns)
+
+    def frames(self):
+        """The frame list of the last finish(), in position order (a copy when it
+        has to be stitched from the per-rank slots)."""
+        if self.gather != "shm":
+            return self.h_frames[:sum(self.ns)]
+        if self.world == 1:
+            return self.slots[0][:self.ns[0]]
+        return np.concatenate([self.slots[q][:self.ns[q]] for q in range(self.world)])
+
+    def step(self, d_iq, nbytes, encoding, base_position, n_owned, reset=True):
+        """One pass over this rank's shard: begin, exchange, finish."""
+        self.begin(d_iq, nbytes, encoding, base_position, n_owned, reset=reset)
+        self.exchange()
+        return self.finish()

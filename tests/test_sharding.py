@@ -71,13 +71,20 @@ class OracleContext:
                               c["amplitude_56"], c["syndrome"], c["address"], 0, c["df"],
                               -1, FRAME_ACCEPTED | (FRAME_SQUITTER if squitter else 0), 0)
 
+    def frame_count(self):
+        return len(self.frames)
+
+    def collect_into(self, out):
+        out[:len(self.frames)] = self.frames
+        return len(self.frames)
+
     def collect_device(self, d_out, cap):
         raw = torch.from_numpy(self.frames.view(np.uint8).copy())
         d_out[:raw.numel()] = raw
         return len(self.frames)
 
 
-def _worker(rank, world, port, raw, result_path):
+def _worker(rank, world, port, raw, result_path, gather):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -86,11 +93,26 @@ def _worker(rank, world, port, raw, result_path):
         first, owned, local = plan_shards(total, world)[rank]
         shard = torch.frombuffer(bytearray(raw[2 * first:2 * (first + local)]),
                                  dtype=torch.uint8)
-        dec = ShardedDecoder(OracleContext(), rank, world, torch.device("cpu"), 20000)
-        for _ in range(2):                      # twice: reset between captures works
-            n = dec.step(shard, 2 * local, ob.ENC_UC8, first, owned)
+        # two decoders interleaved the way bench.py pipelines them
+        decs = [ShardedDecoder(OracleContext(), rank, world, torch.device("cpu"), 20000,
+                               gather=gather) for _ in range(2)]
+        args = (shard, 2 * local, ob.ENC_UC8, first, owned)
+        decs[0].begin(*args)
+        decs[0].exchange()
+        decs[1].begin(*args)
+        n0 = decs[0].finish()
+        decs[1].exchange()
+        decs[0].begin(*args)                    # again: reset between captures works
+        n1 = decs[1].finish()
+        decs[0].exchange()
+        n = decs[0].finish()
+        assert n0 == n1 == n
         if rank == 0:
-            np.save(result_path, dec.h_frames[:n].copy())
+            assert np.array_equal(decs[0].frames(), decs[1].frames())
+            assert len(decs[0].frames()) == n
+            np.save(result_path, decs[0].frames().copy())
+        for d in decs:
+            d.close()
     finally:
         dist.destroy_process_group()
 
@@ -104,7 +126,8 @@ def test_plan_shards():
 
 
 @pytest.mark.timeout(300)
-def test_two_ranks_equal_one(tmp_path):
+@pytest.mark.parametrize("gather", ["shm", "collective"])
+def test_two_ranks_equal_one(tmp_path, gather):
     p = synth.default_params(2, n_samples=300000, mean_gap=900, reply_permille=300,
                              unknown_permille=250, n_icao=5, seed=21)
     raw = synth.fill_host(p.n_samples, p.encoding, p.seed, synth.make_frames(p)).tobytes()
@@ -118,7 +141,7 @@ def test_two_ranks_equal_one(tmp_path):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     out = str(tmp_path / "frames.npy")
-    mp.spawn(_worker, args=(2, port, raw, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, raw, out, gather), nprocs=2, join=True)
     got = np.load(out)
     assert [int(f["position"]) for f in got] == [c["position"] for c in want]
     from sora_amd import bits_to_string
