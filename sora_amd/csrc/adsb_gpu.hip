@@ -190,7 +190,7 @@ sora_adsb_reset(sora_adsb_ctx *ctx) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, sora_launch_fill_u64(ctx->d_first_seen, ~0ull, SORA_ADDRESSES,
 	    ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_known_bits, 0, SORA_ADDRESSES / 8,
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_known_bits, 0, SORA_KNOWN_WORDS * sizeof(uint32_t),
 	    ctx->stream));
     ctx->scanned = ctx->resolved = false;
     return SORA_OK;
@@ -253,7 +253,7 @@ sora_adsb_create(sora_adsb_ctx **out, int device, const sora_adsb_config *cfg) {
     const uint32_t nr = ctx->max_regions;
     if (dev_alloc(&ctx->d_rec, ctx->rec_total) != hipSuccess ||
 	    dev_alloc(&ctx->d_acc_flat, ctx->frames_cap) != hipSuccess ||
-	    dev_alloc(&ctx->d_known_bits, SORA_ADDRESSES / 32) != hipSuccess ||
+	    dev_alloc(&ctx->d_known_bits, SORA_KNOWN_WORDS) != hipSuccess ||
 	    dev_alloc(&ctx->d_sq, ctx->sq_total) != hipSuccess ||
 	    dev_alloc(&ctx->d_acc, ctx->acc_total) != hipSuccess ||
 	    dev_alloc(&ctx->d_frames, ctx->frames_cap) != hipSuccess ||

@@ -23,6 +23,11 @@
 #define SORA_STAT_WORDS		5
 #endif
 
+#define SORA_KNOWN_BITMAP_WORDS	(1u << 19)	/* 2^24 addresses */
+#define SORA_KNOWN_FOLD_BITS	17
+#define SORA_KNOWN_FOLD_WORDS	(1u << (SORA_KNOWN_FOLD_BITS - 5))	/* 16 KB */
+#define SORA_KNOWN_WORDS	(SORA_KNOWN_BITMAP_WORDS + SORA_KNOWN_FOLD_WORDS)
+
 struct sora_scan_args {
     const uint8_t *iq;		/* device, 16-byte aligned */
     uint64_t n_samples;		/* samples in the chunk */
@@ -54,7 +59,9 @@ struct sora_resolve_args {
     const uint32_t *sq_count;
     uint32_t sq_cap;
     uint64_t *first_seen;	/* [1 << 24] smallest global position, or ~0 */
-    uint32_t *known_bits;	/* [1 << 19] bitmap of the addresses in first_seen */
+    uint32_t *known_bits;	/* [SORA_KNOWN_WORDS] bitmap of the addresses in
+				 * first_seen, then its 2^17-bit fold
+				 * (bit addr & 0x1ffff) for the filter's LDS */
     uint32_t regions;		/* accepted regions: sora_filter_regions(groups) */
     uint64_t *acc;		/* [regions][acc_cap] accepted records */
     uint32_t *acc_count;	/* [regions] */

@@ -481,6 +481,11 @@ note_known(uint64_t *first_seen, uint32_t *known_bits, uint32_t addr,
     const uint32_t bit = 1u << (addr & 31);
     if ((known_bits[addr >> 5] & bit) == 0)
 	atomicOr(&known_bits[addr >> 5], bit);
+    /* the fold: same bit of word (addr mod 2^17) / 32 */
+    uint32_t *fold = known_bits + SORA_KNOWN_BITMAP_WORDS;
+    const uint32_t w = (addr & ((1u << SORA_KNOWN_FOLD_BITS) - 1)) >> 5;
+    if ((fold[w] & bit) == 0)
+	atomicOr(&fold[w], bit);
 }
 
 /* one block per workgroup region of the scan */
@@ -581,10 +586,14 @@ export_squitters_kernel(sora_resolve_args a, const uint64_t *offsets,
  * barriers, four independent record loads in flight per lane.
  */
 constexpr int kFilterWaves = kSmall / 64;
-constexpr int kFilterUnroll = 4;
+constexpr int kFilterUnroll = 8;
 
 __global__ void __launch_bounds__(kSmall)
 filter_kernel(sora_resolve_args a) {
+    /* the 2^17-bit fold of the known-address bitmap: with a few hundred planes
+     * known it passes a fraction of a percent of the noise replies, and only
+     * those go on to the exact bitmap and the first-seen table in L2 */
+    __shared__ uint32_t s_fold[SORA_KNOWN_FOLD_WORDS];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t group = blockIdx.x;
     const uint32_t region = group * kFilterWaves + wave;
@@ -592,6 +601,14 @@ filter_kernel(sora_resolve_args a) {
     uint64_t *acc = a.acc + (uint64_t) region * a.acc_cap;
     uint32_t n = a.rec_count[group];
     uint32_t n_acc = 0;
+
+    {
+	const u32x4 *src = reinterpret_cast<const u32x4 *>(a.known_bits +
+		SORA_KNOWN_BITMAP_WORDS);
+	for (uint32_t i = threadIdx.x; i < SORA_KNOWN_FOLD_WORDS / 4; i += kSmall)
+	    *reinterpret_cast<u32x4 *>(&s_fold[4 * i]) = src[i];
+    }
+    __syncthreads();
 
     if (n > a.rec_cap)
 	n = a.rec_cap;
@@ -604,33 +621,35 @@ filter_kernel(sora_resolve_args a) {
 #pragma unroll
 	for (int u = 0; u < kFilterUnroll; u++) {
 	    const uint32_t i = base + u * 64 + lane;
-	    r[u] = i < end? rec[i] : ~0ull;
+	    r[u] = i < end? rec[i] : ~0ull;	/* kind 15: dropped below */
 	}
 #pragma unroll
 	for (int u = 0; u < kFilterUnroll; u++) {
-	    const uint32_t i = base + u * 64 + lane;
 	    const uint32_t kind = sora_rec_kind(r[u]);
 	    keep[u] = false;
-	    if (i < end) {
-		if (kind == SORA_REC_KIND_SQUITTER || kind == SORA_REC_KIND_CORRECTED) {
-		    keep[u] = true;
+	    if (kind == SORA_REC_KIND_SQUITTER || kind == SORA_REC_KIND_CORRECTED) {
+		keep[u] = true;
+		r[u] |= SORA_REC_ACCEPTED << 60;
+	    } else if (kind == SORA_REC_KIND_REPLY) {
+		const uint32_t addr = sora_rec_addr(r[u]);
+		const uint32_t f = addr & ((1u << SORA_KNOWN_FOLD_BITS) - 1);
+		bool known = (s_fold[f >> 5] >> (addr & 31)) & 1;
+		if (known)
+		    known = (a.known_bits[addr >> 5] >> (addr & 31)) & 1;
+		if (known)
+		    known = a.first_seen[addr] < a.base_position + sora_rec_pos(r[u]);
+		if (known)
 		    r[u] |= SORA_REC_ACCEPTED << 60;
-		} else if (kind == SORA_REC_KIND_REPLY) {
-		    const uint32_t addr = sora_rec_addr(r[u]);
-		    bool known = (a.known_bits[addr >> 5] >> (addr & 31)) & 1;
-		    if (known)
-			known = a.first_seen[addr] < a.base_position + sora_rec_pos(r[u]);
-		    if (known)
-			r[u] |= SORA_REC_ACCEPTED << 60;
-		    keep[u] = known || a.emit_all;
-		} else {
-		    keep[u] = a.emit_all != 0;
-		}
+		keep[u] = known || a.emit_all;
+	    } else if (kind == SORA_REC_KIND_DIRTY) {
+		keep[u] = a.emit_all != 0;
 	    }
 	}
 #pragma unroll
 	for (int u = 0; u < kFilterUnroll; u++) {
 	    const unsigned long long m = __ballot(keep[u]);
+	    if (m == 0)
+		continue;
 	    if (keep[u]) {
 		const uint32_t idx = n_acc + rank_in_mask(m);
 		if (idx < a.acc_cap)
@@ -681,13 +700,15 @@ magnitude_f32(const uint8_t *iq, uint64_t i, int encoding) {
 	const uint32_t w = reinterpret_cast<const uint32_t *>(iq)[i];
 	return __uint_as_float(sora_mag_sc16(w)) * (1.0f / 1073741824.0f);
     }
+    /* one 16-bit load per sample (I in the low byte) */
+    const uint32_t w = reinterpret_cast<const uint16_t *>(iq)[i];
     int vi, vq;
     if (encoding == SORA_ENC_UC8) {
-	vi = (int) iq[2 * i] - 128;
-	vq = (int) iq[2 * i + 1] - 128;
+	vi = (int) (w & 0xff) - 128;
+	vq = (int) (w >> 8) - 128;
     } else {
-	vi = (int8_t) iq[2 * i];
-	vq = (int8_t) iq[2 * i + 1];
+	vi = (int8_t) (w & 0xff);
+	vq = (int8_t) (w >> 8);
     }
     return (float) (vi * vi + vq * vq) * (1.0f / 16384.0f);
 }
@@ -697,18 +718,31 @@ struct frame_mags {
     float a0, a1, b0, b1;
 };
 
-__device__ __forceinline__ frame_mags
-load_frame_mags(const uint8_t *iq, uint64_t p, uint32_t lane, int encoding) {
+/* straight-line variant of magnitude_f32 for the finalize kernel: the encoding
+ * class is a template parameter, uc8 against sc8 is the xor mask, so that the
+ * compiler can issue the loads of several frames back to back */
+template <bool kWide> __device__ __forceinline__ float
+frame_sample(const uint8_t *iq, uint64_t i, uint32_t flip16) {
+    if constexpr (kWide) {
+	const uint32_t w = reinterpret_cast<const uint32_t *>(iq)[i];
+	return __uint_as_float(sora_mag_sc16(w)) * (1.0f / 1073741824.0f);
+    } else {
+	const uint32_t w = reinterpret_cast<const uint16_t *>(iq)[i] ^ flip16;
+	const int vi = (int8_t) (w & 0xff), vq = (int8_t) (w >> 8);
+	return (float) (vi * vi + vq * vq) * (1.0f / 16384.0f);
+    }
+}
+
+template <bool kWide> __device__ __forceinline__ frame_mags
+load_frame_mags(const uint8_t *iq, uint64_t p, uint32_t lane, uint32_t flip16) {
     frame_mags m;
     const uint64_t s = p + 16;
-    m.a0 = magnitude_f32(iq, s + 2 * lane, encoding);
-    m.a1 = magnitude_f32(iq, s + 2 * lane + 1, encoding);
-    m.b0 = 0;
-    m.b1 = 1;
-    if (lane < 48) {
-	m.b0 = magnitude_f32(iq, s + 128 + 2 * lane, encoding);
-	m.b1 = magnitude_f32(iq, s + 128 + 2 * lane + 1, encoding);
-    }
+    /* lanes 48..63 have no second pair: they re-read their first one */
+    const uint64_t t = lane < 48? s + 128 : s;
+    m.a0 = frame_sample<kWide>(iq, s + 2 * lane, flip16);
+    m.a1 = frame_sample<kWide>(iq, s + 2 * lane + 1, flip16);
+    m.b0 = frame_sample<kWide>(iq, t + 2 * lane, flip16);
+    m.b1 = frame_sample<kWide>(iq, t + 2 * lane + 1, flip16);
     return m;
 }
 
@@ -718,9 +752,29 @@ load_frame_mags(const uint8_t *iq, uint64_t p, uint32_t lane, int encoding) {
  * (plane-iq.c:58-86) and of the CRC (plane.c:373-385), and the only place
  * amplitudes are computed (only accepted frames need them).
  */
+/* the entries of c_crc_pow a lane can need, fetched once per wave */
+struct lane_powers {
+    uint32_t long_lo;	/* x^(111 - lane): bit `lane` of an 88-bit span */
+    uint32_t long_hi;	/* x^(47 - lane): bit 64 + lane, lane < 24 */
+    uint32_t short_lo;	/* x^(55 - lane): bit `lane` of a 32-bit span, lane < 32 */
+    uint32_t own_lo;	/* x^lane and x^(64 + lane): the correction lookup */
+    uint32_t own_hi;
+};
+
+__device__ __forceinline__ lane_powers
+load_lane_powers(uint32_t lane) {
+    lane_powers w;
+    w.long_lo = c_crc_pow.r[111 - lane];
+    w.long_hi = c_crc_pow.r[lane < 24? 47 - lane : 0];
+    w.short_lo = c_crc_pow.r[lane < 32? 55 - lane : 0];
+    w.own_lo = c_crc_pow.r[lane];
+    w.own_hi = c_crc_pow.r[lane < 48? 64 + lane : 0];
+    return w;
+}
+
 __device__ __forceinline__ void
 finalize_one(const sora_resolve_args &a, uint64_t f, uint64_t r, const frame_mags &m,
-	uint32_t lane, float *s_amp) {
+	uint32_t lane, float *s_amp, const lane_powers &w) {
     const uint64_t p = sora_rec_pos(r);
 
     /* bit k = m[p+17+2k] <= m[p+16+2k], k = lane and k = 64 + lane */
@@ -738,9 +792,9 @@ finalize_one(const sora_resolve_args &a, uint64_t f, uint64_t r, const frame_mag
     const int covered = is_long? 88 : 32;
     uint32_t x = 0;
     if ((int) lane < covered && ((lo >> lane) & 1))
-	x = c_crc_pow.r[covered + 23 - lane];
+	x = is_long? w.long_lo : w.short_lo;		/* x^(covered + 23 - lane) */
     if ((int) lane + 64 < covered && ((hi >> lane) & 1))
-	x ^= c_crc_pow.r[covered + 23 - 64 - lane];
+	x ^= w.long_hi;					/* x^(covered + 23 - 64 - lane) */
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1)
 	x ^= __shfl_xor(x, d, 64);
@@ -755,9 +809,8 @@ finalize_one(const sora_resolve_args &a, uint64_t f, uint64_t r, const frame_mag
     int corrected = -1;
     if ((sora_rec_kind(r) & 3) == SORA_REC_KIND_CORRECTED) {
 	const int nbits = is_long? 112 : 56;
-	const unsigned long long k_lo = __ballot(c_crc_pow.r[lane] == syndrome);
-	const unsigned long long k_hi = __ballot(lane < 48 &&
-		c_crc_pow.r[64 + (lane < 48? lane : 0)] == syndrome);
+	const unsigned long long k_lo = __ballot(w.own_lo == syndrome);
+	const unsigned long long k_hi = __ballot(lane < 48 && w.own_hi == syndrome);
 	const int k = k_lo != 0? __builtin_ctzll(k_lo) :
 		k_hi != 0? 64 + __builtin_ctzll(k_hi) : -1;
 	if (k >= 0 && k <= nbits - 6) {
@@ -807,8 +860,13 @@ finalize_one(const sora_resolve_args &a, uint64_t f, uint64_t r, const frame_mag
     __builtin_amdgcn_wave_barrier();
 }
 
+constexpr int kFinalizeDepth = 4;	/* frames whose sample fetches are in flight */
+
+template <bool kWide>
 __global__ void __launch_bounds__(kSmall)
 finalize_kernel(sora_resolve_args a) {
+    const uint32_t flip16 = a.encoding == SORA_ENC_UC8? 0x8080u : 0u;
+    const lane_powers pw = load_lane_powers(threadIdx.x & 63);
     __shared__ float s_amp[kSmall / 64][56];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t n_waves = (uint64_t) gridDim.x * (kSmall / 64);
@@ -817,17 +875,29 @@ finalize_kernel(sora_resolve_args a) {
 
     if (total > a.frames_cap)
 	total = a.frames_cap;
-    /* two frames per trip so that both sample fetches are in flight together */
-    for (uint64_t f = gw; f < total; f += 2 * n_waves) {
-	const uint64_t g = f + n_waves;
-	const bool two = g < total;
-	const uint64_t r0 = a.acc_flat[f];
-	const uint64_t r1 = two? a.acc_flat[g] : r0;
-	const frame_mags m0 = load_frame_mags(a.iq, sora_rec_pos(r0), lane, a.encoding);
-	const frame_mags m1 = load_frame_mags(a.iq, sora_rec_pos(r1), lane, a.encoding);
-	finalize_one(a, f, r0, m0, lane, s_amp[wave]);
-	if (two)
-	    finalize_one(a, g, r1, m1, lane, s_amp[wave]);
+    /* a wave takes 64 consecutive frames at a time: one coalesced load brings
+     * their records (no dependent record fetch per frame), then the sample
+     * fetches of kFinalizeDepth frames are issued together */
+    for (uint64_t batch = gw * 64; batch < total; batch += n_waves * 64) {
+	const uint32_t cnt = total - batch < 64? (uint32_t) (total - batch) : 64u;
+	const uint64_t mine = lane < cnt? a.acc_flat[batch + lane] : 0;
+	const uint32_t mine_lo = (uint32_t) mine, mine_hi = (uint32_t) (mine >> 32);
+
+	for (uint32_t j = 0; j < cnt; j += kFinalizeDepth) {
+	    uint64_t r[kFinalizeDepth];
+	    frame_mags m[kFinalizeDepth];
+#pragma unroll
+	    for (int u = 0; u < kFinalizeDepth; u++) {
+		const uint32_t k = j + u < cnt? j + u : cnt - 1;	/* uniform */
+		r[u] = (uint64_t) (uint32_t) __builtin_amdgcn_readlane((int) mine_lo, (int) k) |
+			((uint64_t) (uint32_t) __builtin_amdgcn_readlane((int) mine_hi, (int) k) << 32);
+		m[u] = load_frame_mags<kWide>(a.iq, sora_rec_pos(r[u]), lane, flip16);
+	    }
+#pragma unroll
+	    for (int u = 0; u < kFinalizeDepth; u++)
+		if (j + u < cnt)
+		    finalize_one(a, batch + j + u, r[u], m[u], lane, s_amp[wave], pw);
+	}
     }
 }
 
@@ -956,7 +1026,12 @@ sora_launch_finalize(const sora_resolve_args *a, uint32_t cus, hipStream_t strea
     /* 8 blocks of 4 waves per CU: every wave slot busy hiding the two
      * dependent fetches (record, then samples) of a frame */
     (void) hipGetLastError();
-    hipLaunchKernelGGL(finalize_kernel, dim3(cus * 8), dim3(kSmall), 0, stream, *a);
+    if (a->encoding == SORA_ENC_SC16)
+	hipLaunchKernelGGL(finalize_kernel<true>, dim3(cus * 8), dim3(kSmall), 0,
+		stream, *a);
+    else
+	hipLaunchKernelGGL(finalize_kernel<false>, dim3(cus * 8), dim3(kSmall), 0,
+		stream, *a);
     return hipGetLastError();
 }
 
