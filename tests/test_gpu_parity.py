@@ -442,3 +442,76 @@ def test_config5_batched_archive():
         ob.scan(recs[2][1], recs[2][0], plane_set=ps)
         want = [c for c in ob.scan(raw, enc, plane_set=ps) if c["accepted"]]
         assert_same_frames(frames_as_dicts(leaked), want)
+
+
+def test_config2_full_size_properties():
+    """BASELINE configs[1] at its full size (7.2 G samples, 14.4 GB; positions
+    pass 2^32): idempotence, order, recovery of the strong injected frames, a
+    window behind position 2^32 against the oracle exactly, and the capture as
+    two time shards with the squitter exchange (configs[2] with two ranks on one
+    device) equal to the whole."""
+    import torch
+    free, _ = torch.cuda.mem_get_info()
+    if free < 60 << 30:
+        pytest.skip("needs 60 GB of free HBM")
+    p = synth.default_params(2)
+    assert p.n_samples == 7200000000
+    fr = synth.make_frames(p)
+    n = p.n_samples
+    d = torch.empty(2 * n + 16, dtype=torch.uint8, device="cuda")
+    synth.fill_device(d.data_ptr(), n, p.encoding, p.seed, fr)
+    cap = n // 1024 + 65536
+    with AdsbContext(n, max_squitters=cap, max_frames=cap) as ctx:
+        ctx.submit_device(d, 2 * n, ENC_UC8)
+        a = ctx.collect()
+        counts = ctx.counts()
+        ctx.reset()
+        ctx.submit_device(d, 2 * n, ENC_UC8)
+        b = ctx.collect()
+    assert a.tobytes() == b.tobytes()
+    pos = a["position"].astype(np.int64)
+    assert np.all(np.diff(pos) > 0) and pos[-1] > (1 << 32)
+    assert counts["frames"] == len(a)
+    assert counts["candidates"] == counts["replies"] + counts["squitters"] + \
+        counts["dirty_squitters"]
+    # strong frames (amplitude >= 40 counts) are found where they were put
+    got = dict(zip(pos.tolist(), range(len(a))))
+    strong = [f for f in fr if int(f["kind"]) in (synth.KIND_DF17, synth.KIND_DF11)
+              and int(f["amp_i"]) >= 40][::50]
+    def same(f):                            # a short frame's bits 56.. are noise
+        g = a[got[int(f["position"])]]["bits"]
+        w = 4 if int(f["nbits"]) == 112 else 1
+        return np.array_equal(g[:w], f["bits"][:w])
+    hit = sum(1 for f in strong if int(f["position"]) in got and same(f))
+    assert hit >= 0.9 * len(strong)
+    # 3 M samples behind 2^32 against the oracle
+    lo, m = (1 << 32) + 123456, 3000000
+    raw = d[2 * lo:2 * (lo + m)].cpu().numpy().tobytes()
+    ps = ob.PlaneSet()
+    for f in a[pos < lo]:
+        if int(f["flags"]) & sora_amd.FRAME_SQUITTER:
+            ps.parse(sora_amd.bits_to_string(f["bits"]))
+    want = [c for c in ob.scan(raw, base_position=lo, plane_set=ps) if c["accepted"]]
+    assert len(want) > 300
+    assert_same_frames(frames_as_dicts(a[(pos >= lo) & (pos < lo + m - 239)]), want)
+    # two shards, squitter records exchanged
+    half = n // 2
+    shards = [(0, half, half + 239), (half, n - half, n - half)]
+    ctxs = [AdsbContext(half + 239, max_squitters=cap, max_frames=cap) for _ in shards]
+    recs = []
+    for ctx, (s, owned, k) in zip(ctxs, shards):
+        ctx.scan(d.data_ptr() + 2 * s, 2 * k, ENC_UC8, base_position=s, n_owned=owned)
+        c = ctx.squitter_count()
+        t = torch.zeros(max(c, 1), dtype=torch.int64, device="cuda")
+        ctx.copy_squitters(t, c)
+        ctx.synchronize()
+        recs.append((t, c))
+    parts = []
+    for i, ctx in enumerate(ctxs):
+        for j, (t, c) in enumerate(recs):
+            if j != i:
+                ctx.add_known(t, c)
+        ctx.resolve()
+        parts.append(ctx.collect())
+        ctx.close()
+    assert np.concatenate(parts).tobytes() == a.tobytes()
