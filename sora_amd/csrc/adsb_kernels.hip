@@ -394,7 +394,12 @@ adsb_scan_kernel(sora_scan_args a) {
 			    payload ^= 1u << (31 - b);
 		    }
 		}
-		const uint64_t record = sora_rec_make(kind, tile_start + q, payload);
+		/* sora_rec_make(kind, tile_start + q, payload) with the uniform
+		 * part kept scalar: five VALU instructions */
+		const uint32_t rec_lo = (q << 24) | payload;
+		const uint32_t rec_hi = (q >> 8) | ((uint32_t) kind << 28);
+		const uint64_t record = (tile_start << 24) +
+			(((uint64_t) rec_hi << 32) | rec_lo);
 		const uint32_t idx = n_rec + i;
 		if (idx < a.rec_cap)
 		    rec_out[idx] = record;

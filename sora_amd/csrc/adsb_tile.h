@@ -488,22 +488,32 @@ struct sora_candidate {
     uint32_t address;	/* bits[8,32) for squitters, syndrome otherwise */
 };
 
-/* 112 consecutive elements starting at element e of an MSB-first bit array */
+/* (hi:lo) >> s, low word; s in 0..31: one v_alignbit_b32 */
+SORA_HD uint32_t
+sora_funnel(uint32_t hi, uint32_t lo, uint32_t s) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbit(hi, lo, s);
+#else
+    return s == 0? lo : (hi << (32 - s)) | (lo >> s);
+#endif
+}
+
+/*
+ * 112 consecutive elements starting at element e >= 1 of an MSB-first bit
+ * array.  With w = ceil(e / 32) and s = -e mod 32, window k is the funnel
+ * (A[w-1+k] : A[w+k]) >> s for every e, a word-aligned start (s = 0) included:
+ * five words, four v_alignbit_b32, no special case.
+ */
 SORA_HD void
 sora_extract_bits(const uint32_t *words, uint32_t e, uint32_t bits[4]) {
-    uint32_t w0 = e >> 5, sh = e & 31;
-    uint32_t a0 = words[w0], a1 = words[w0 + 1], a2 = words[w0 + 2],
-	    a3 = words[w0 + 3], a4 = words[w0 + 4];
+    const uint32_t w = (e + 31) >> 5, s = (0u - e) & 31;
+    const uint32_t a0 = words[w - 1], a1 = words[w], a2 = words[w + 1],
+	    a3 = words[w + 2], a4 = words[w + 3];
 
-    if (sh == 0) {
-	bits[0] = a0; bits[1] = a1; bits[2] = a2; bits[3] = a3;
-    } else {
-	bits[0] = (a0 << sh) | (a1 >> (32 - sh));
-	bits[1] = (a1 << sh) | (a2 >> (32 - sh));
-	bits[2] = (a2 << sh) | (a3 >> (32 - sh));
-	bits[3] = (a3 << sh) | (a4 >> (32 - sh));
-    }
-    bits[3] &= 0xffff0000u;
+    bits[0] = sora_funnel(a0, a1, s);
+    bits[1] = sora_funnel(a1, a2, s);
+    bits[2] = sora_funnel(a2, a3, s);
+    bits[3] = sora_funnel(a3, a4, s) & 0xffff0000u;
 }
 
 /* plane.c:461-484 up to, but excluding, the plane-set lookup.
