@@ -113,9 +113,9 @@ class ShardedDecoder:
         self.ns = [0] * world
         self._registered = None
         self._mm = None
-        if gather == "shm":
-            self._open_segment()
-        else:
+        if gather == "shm" and not self._open_segment():
+            self.gather = gather = "collective"  # no room in /dev/shm on this node
+        if gather != "shm":
             self.d_gather = ([torch.zeros_like(self.d_out) for _ in range(world)]
                              if rank == 0 else None)
             n_host = self.max_frames * (world if rank == 0 else 1)
@@ -132,10 +132,17 @@ class ShardedDecoder:
         nbytes += -nbytes % (2 << 20)
         name = [None]
         if self.rank == 0:
-            name[0] = f"/dev/shm/sora_frames_{os.getpid()}_{id(self):x}"
-            with open(name[0], "wb") as fh:
-                fh.truncate(nbytes)              # zero filled: seq = ack = 0
+            try:
+                vfs = os.statvfs("/dev/shm")
+                if vfs.f_bavail * vfs.f_frsize > 2 * nbytes:
+                    name[0] = f"/dev/shm/sora_frames_{os.getpid()}_{id(self):x}"
+                    with open(name[0], "wb") as fh:
+                        fh.truncate(nbytes)      # zero filled: seq = ack = 0
+            except OSError:
+                name[0] = None
         dist.broadcast_object_list(name, src=0, group=self.group)
+        if name[0] is None:
+            return False
         self._mm = np.memmap(name[0], dtype=np.uint8, mode="r+", shape=(nbytes,))
         dist.barrier(group=self.group)           # every rank has it mapped
         if self.rank == 0:
@@ -159,6 +166,7 @@ class ShardedDecoder:
                                          pin_memory=self.cuda)
             base = self.data_at + self.rank * self.slot_bytes
             self.h_slot_t = torch.from_numpy(self._mm)[base:base + self.slot_bytes]
+        return True
 
     def close(self):
         if self._registered is not None:
