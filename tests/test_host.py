@@ -105,3 +105,47 @@ def test_sora_file_option_and_emit_all(tmp_path):
     assert out == text["decoded"]
     out = run_sora(["-d", "--adsb-from-raw", "--file=-"], raw)
     assert out == text["decoded"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("encname", ["sc8", "sc16"])
+def test_sora_file_encodings_match_oracle(tmp_path, encname):
+    """--file / --file-encoding routing for sc8 and sc16.
+    Parity unpinned by the reference (it has no such route): the oracle's main
+    loop on the same samples is the expected text."""
+    import oracle_binding as ob
+    from sora_amd import synth
+    enc = {"sc8": ob.ENC_SC8, "sc16": ob.ENC_SC16}[encname]
+    p = synth.default_params(4 if encname == "sc16" else 2, n_samples=400000, mean_gap=800,
+                             reply_permille=250, unknown_permille=200, n_icao=5, seed=12)
+    p.encoding = enc
+    raw = synth.fill_host(p.n_samples, enc, p.seed, synth.make_frames(p)).tobytes()
+    path = tmp_path / f"capture.{encname}"
+    path.write_bytes(raw)
+    for flags, extra in ((0x11, []), (0x21, ["--adsb-to-bitstring"])):
+        want = ob.main_loop_text(raw, flags, enc)
+        assert want.count("\n") > 50
+        got = run_sora(["-d", "--adsb-from-raw", f"--file={path}",
+                        f"--file-encoding={encname}"] + extra, b"",
+                       {"SORA_ADSB_BLOCK_SAMPLES": "70000"})
+        assert got == want
+
+
+@pytest.mark.gpu
+def test_sora_correction_env_matches_oracle():
+    """SORA_ADSB_CORRECT=1 (section 8 f.3): corrected squitters reach the plane set
+    and the printer exactly as in the oracle's main loop with correction on."""
+    import oracle_binding as ob
+    from sora_amd import synth
+    p = synth.default_params(4, n_samples=600000, seed=4)       # 20 % one-bit errors
+    p.encoding = ob.ENC_UC8
+    p.amp_min, p.amp_max = 30, 110
+    raw = synth.fill_host(p.n_samples, p.encoding, p.seed, synth.make_frames(p)).tobytes()
+    plain = ob.main_loop_text(raw, 0x21)
+    fixed = ob.main_loop_text(raw, 0x21, correct=True)
+    assert fixed.count("\n") > plain.count("\n") + 50
+    args = ["-d", "--adsb-from-raw", "--adsb-to-bitstring"]
+    assert run_sora(args, raw) == plain
+    assert run_sora(args, raw, {"SORA_ADSB_CORRECT": "1"}) == fixed
+    assert run_sora(["-d", "--adsb-from-raw"], raw, {"SORA_ADSB_CORRECT": "1"}) == \
+        ob.main_loop_text(raw, 0x11, correct=True)
