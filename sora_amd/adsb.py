@@ -83,7 +83,11 @@ class AdsbContext:
             lib().sora_adsb_destroy(self._h)
             self._h = None
 
-    __del__ = close
+    def __del__(self):
+        try:                    # at interpreter shutdown the module globals may be gone
+            self.close()
+        except Exception:
+            pass
 
     def __enter__(self):
         return self

@@ -130,6 +130,17 @@ wave_inclusive_scan(uint32_t v) {
     return v;
 }
 
+/*
+ * Barrier of the scan kernel's tile loop.  Everything the workgroup shares is
+ * in LDS, so only LDS traffic has to have landed: __syncthreads() also waits
+ * for vmcnt(0), i.e. for the record stores of phase 4 and for loads issued
+ * ahead, a memory round trip per tile that nothing needs.
+ */
+__device__ __forceinline__ void
+lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 /* ------------------------------------------------------------------ scan -- */
 
 /*
@@ -196,6 +207,25 @@ adsb_scan_kernel(sora_scan_args a) {
     const uint32_t *w_nue = reinterpret_cast<const uint32_t *>(s_nue);
     const uint32_t *w_nuo = reinterpret_cast<const uint32_t *>(s_nuo);
 
+    /* the raw samples of a tile, 16 bytes per lane and load.  (Issuing them a
+     * tile ahead, under phases 3 and 4, was measured 20 % SLOWER: the 16 extra
+     * live registers spill, and every spill reload waits for the loads.) */
+    auto load_tile = [&](u32x4 *v, uint64_t tile_no, uint32_t lane16) {
+	const uint64_t start = tile_no * kTilePos;
+	uint64_t left = (a.n_samples - start) * G::bytes_per_sample;
+	left = (left + 3) & ~3ull;		/* see sora_adsb_scan(): an odd
+						 * sample count reads its last dword whole */
+	const uint32_t span = left < (uint64_t) G::tile_bytes?
+		(uint32_t) left : (uint32_t) G::tile_bytes;
+	auto rsrc = __builtin_amdgcn_make_buffer_rsrc(
+		const_cast<uint8_t *>(a.iq) + start * G::bytes_per_sample, 0, span,
+		0x00020000);
+#pragma unroll
+	for (int r = 0; r < kLoads; r++)
+	    v[r] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane16,
+		    r * kThreads * 16, 0);
+    };
+
     for (uint64_t tile = tile_begin; tile < tile_end; tile++) {
 	const uint64_t tile_start = tile * kTilePos;
 	/* the thread index, made opaque once per tile: LDS addresses derived from
@@ -208,19 +238,8 @@ adsb_scan_kernel(sora_scan_args a) {
 
 	/* ---- phase 1: load, magnitude, LDS ---- */
 	{
-	    uint64_t left = (a.n_samples - tile_start) * G::bytes_per_sample;
-	    left = (left + 3) & ~3ull;		/* see sora_adsb_scan(): an odd
-						 * sample count reads its last dword whole */
-	    uint32_t span = left < (uint64_t) G::tile_bytes?
-		    (uint32_t) left : (uint32_t) G::tile_bytes;
-	    auto rsrc = __builtin_amdgcn_make_buffer_rsrc(
-		    const_cast<uint8_t *>(a.iq) + tile_start * G::bytes_per_sample, 0,
-		    span, 0x00020000);
 	    u32x4 v[kLoads];
-#pragma unroll
-	    for (int r = 0; r < kLoads; r++)
-		v[r] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, t * 16,
-			r * kThreads * 16, 0);
+	    load_tile(v, tile, t * 16);
 	    STAMP_WAIT_VM();
 	    STAMP(0);			/* HBM latency of the tile's loads */
 #pragma unroll
@@ -248,7 +267,7 @@ adsb_scan_kernel(sora_scan_args a) {
 	}
 	STAMP_WAIT_LDS();
 	STAMP(1);			/* magnitudes + LDS stores */
-	__syncthreads();
+	lds_barrier();
 	STAMP(2);			/* barrier 1 */
 
 	/* ---- phase 2: compare bits of this lane's 32 positions ---- */
@@ -295,7 +314,7 @@ adsb_scan_kernel(sora_scan_args a) {
 	    s_de[kThreads + tid] = 0;
 	    s_do[kThreads + tid] = 0;
 	}
-	__syncthreads();	/* M is dead from here on: s_m becomes queue + CRC table */
+	lds_barrier();	/* M is dead from here on: s_m becomes queue + CRC table */
 	STAMP(4);			/* word stores + barrier 2 */
 
 	/* ---- phase 3: predicate words, ordered queue of hits ---- */
@@ -340,7 +359,7 @@ adsb_scan_kernel(sora_scan_args a) {
 		*reinterpret_cast<u32x4 *>(&s_crc[4 * c * kThreads + 4 * t]) = tab[c];
 	if (tid == 0)
 	    s_sq_count = 0;
-	__syncthreads();
+	lds_barrier();
 	uint32_t total = 0, off = incl - cnt;
 #pragma unroll
 	for (int w = 0; w < kWaves; w++) {
@@ -359,7 +378,7 @@ adsb_scan_kernel(sora_scan_args a) {
 		both &= ~bit;
 	    }
 	}
-	__syncthreads();
+	lds_barrier();
 	STAMP(5);			/* predicate, block scan, queue (2 barriers) */
 
 	/* ---- phase 4: one lane per candidate ----
@@ -416,7 +435,7 @@ adsb_scan_kernel(sora_scan_args a) {
 	    }
 	}
 	n_rec += total;
-	__syncthreads();
+	lds_barrier();
 	n_sq += s_sq_count;
 	/* every lane has passed a barrier after its last read of the queue,
 	 * the CRC tables and the NU arrays, so the next tile may refill them;
