@@ -49,7 +49,7 @@ template <> struct tile_geom<false> {		/* uc8, sc8: 16-bit magnitudes */
     static constexpr int m_dwords = SORA_M_DWORDS;
     static constexpr int m_tail = 4;		/* zeroed dwords behind the last lane */
     static constexpr int words = SORA_WORDS;
-    static constexpr int waves_per_simd = 6;	/* 3 workgroups of 8 waves per CU */
+    static constexpr int waves_per_simd = 6;	/* 24 waves per CU */
 };
 template <> struct tile_geom<true> {		/* sc16: 32-bit magnitudes */
     static constexpr int threads = SORA16_TILE_THREADS;
@@ -176,10 +176,11 @@ adsb_scan_kernel(sora_scan_args a) {
     constexpr int kTilePos = G::tile_pos;
     constexpr int kQueueMax = kTilePos / 2;		/* p and p+1 never both hit */
     constexpr int kCrcTableDword = (kQueueMax / 2 + 63) & ~63;	/* past the queue */
-    static_assert(kCrcTableDword + SORA_CRC_TABLE_WORDS + SORA_FIX_TABLE_WORDS <=
-	    G::m_dwords, "CRC tables outside M buffer");
+    /* the buffer holds M in phases 1-2, then the queue and the tables */
+    constexpr int kAfterM = kCrcTableDword + SORA_CRC_TABLE_WORDS + SORA_FIX_TABLE_WORDS;
+    constexpr int kBufDwords = G::m_dwords > kAfterM? G::m_dwords : kAfterM;
 
-    __shared__ __attribute__((aligned(16))) uint32_t s_m[G::m_dwords];
+    __shared__ __attribute__((aligned(16))) uint32_t s_m[kBufDwords];
     /* bit arrays, written as 16-bit halves (one per lane), read as 32-bit words */
     __shared__ __attribute__((aligned(4))) uint16_t s_bits[4][2 * G::words];
     uint16_t *const s_nue = s_bits[0], *const s_nuo = s_bits[1];
@@ -953,7 +954,7 @@ sora_scan_tiles(uint64_t n_scan, int encoding) {
 uint32_t
 sora_scan_groups_per_cu(int encoding) {
     /* workgroups of one CU: bounded by LDS (45 KB and 39 KB per workgroup) */
-    return encoding == SORA_ENC_SC16? 4 : 3;
+    return encoding == SORA_ENC_SC16? 4 : 3 * 512 / SORA_TILE_THREADS;
 }
 
 hipError_t

@@ -35,10 +35,12 @@
 #endif
 
 /* ---- tile geometry for the 8-bit encodings ---- */
+#ifndef SORA_TILE_THREADS
 #define SORA_TILE_THREADS	512
+#endif
 #define SORA_LANE_PAIRS		16		/* pairs (dwords of M) per lane */
 #define SORA_LANE_POS		32		/* positions per lane */
-#define SORA_OWN_LANES		504		/* lanes whose positions a tile owns */
+#define SORA_OWN_LANES		(SORA_TILE_THREADS - 8)	/* lanes whose positions a tile owns */
 #define SORA_TILE_POS		(SORA_OWN_LANES * SORA_LANE_POS)	/* 16128 */
 #define SORA_TILE_SAMPLES	(SORA_TILE_THREADS * SORA_LANE_POS)	/* 16384 */
 /* M in LDS: lane g's 16 dwords start at dword 20*g (4 dwords of padding keep
