@@ -504,13 +504,13 @@ note_known(uint64_t *first_seen, uint32_t *known_bits, uint32_t addr,
 	atomicMin(reinterpret_cast<unsigned long long *>(&first_seen[addr]),
 		(unsigned long long) position);
     const uint32_t bit = 1u << (addr & 31);
-    if ((known_bits[addr >> 5] & bit) == 0)
-	atomicOr(&known_bits[addr >> 5], bit);
-    /* the fold: same bit of word (addr mod 2^17) / 32 */
-    uint32_t *fold = known_bits + SORA_KNOWN_BITMAP_WORDS;
-    const uint32_t w = (addr & ((1u << SORA_KNOWN_FOLD_BITS) - 1)) >> 5;
-    if ((fold[w] & bit) == 0)
-	atomicOr(&fold[w], bit);
+    if ((known_bits[addr >> 5] & bit) == 0 &&
+	    (atomicOr(&known_bits[addr >> 5], bit) & bit) == 0) {
+	/* the thread that set the bit also sets it in the fold: same bit of
+	 * word (addr mod 2^17) / 32 */
+	uint32_t *fold = known_bits + SORA_KNOWN_BITMAP_WORDS;
+	atomicOr(&fold[(addr & ((1u << SORA_KNOWN_FOLD_BITS) - 1)) >> 5], bit);
+    }
 }
 
 /* one block per workgroup region of the scan */
