@@ -148,10 +148,14 @@ int sora_adsb_scan(sora_adsb_ctx *ctx, const void *d_iq, size_t nbytes,
 	int encoding, uint64_t base_position, uint64_t n_owned);
 
 /*
- * Exchange step for time-sharded captures: the clean
- * squitters of the last scan as 8-byte records (position << 24 | address),
- * copied to a DEVICE buffer the caller owns, and records of other shards
- * merged into this context's first-seen table.  Both asynchronous.
+ * Exchange step for time-sharded captures.  What the
+ * other shards need from this one is, per address, the earliest clean squitter
+ * of the last scan: 8-byte records (position << 24 | address), one per address
+ * this scan saw first (a few hundred per hour, not every squitter).
+ * squitter_count merges the scan's squitters into the first-seen table, builds
+ * that list and returns its length (synchronizes); copy_squitters copies it to
+ * a DEVICE buffer the caller owns; add_known merges records of other shards
+ * into this context's table.  The copies are asynchronous.
  */
 int sora_adsb_squitter_count(sora_adsb_ctx *ctx, uint64_t *n); /* syncs */
 int sora_adsb_copy_squitters(sora_adsb_ctx *ctx, void *d_dst, size_t cap_records);

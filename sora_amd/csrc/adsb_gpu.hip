@@ -45,6 +45,10 @@ struct sora_adsb_ctx {
 
     /* the chunk in flight */
     bool scanned, resolved;
+    bool merged;		/* its squitters are in first_seen */
+    bool exported;		/* d_export holds its first-seen records */
+    uint64_t *d_export;		/* one record per address first seen in this scan */
+    uint64_t export_cap;
     sora_scan_args scan;
     sora_resolve_args res;
     uint32_t groups;
@@ -165,6 +169,7 @@ sora_adsb_destroy(sora_adsb_ctx *ctx) {
     (void) hipFree(ctx->d_stats);
     (void) hipFree(ctx->d_acc_offset);
     (void) hipFree(ctx->d_sq_offset);
+    (void) hipFree(ctx->d_export);
     (void) hipFree(ctx->d_rec_count);
     (void) hipFree(ctx->d_sq_count);
     (void) hipFree(ctx->d_acc_count);
@@ -248,6 +253,8 @@ sora_adsb_create(sora_adsb_ctx **out, int device, const sora_adsb_config *cfg) {
     ctx->acc_total = cfg->max_frames != 0? cfg->max_frames :
 	    cfg->emit_mode == SORA_EMIT_CANDIDATES? ctx->rec_total : ctx->sq_total;
     ctx->frames_cap = ctx->acc_total;
+    /* at most one export record per address, and never more than squitters */
+    ctx->export_cap = ctx->sq_total < (1ull << 22)? ctx->sq_total : (1ull << 22);
 
     const uint32_t g = ctx->max_groups;
     const uint32_t nr = ctx->max_regions;
@@ -261,6 +268,7 @@ sora_adsb_create(sora_adsb_ctx **out, int device, const sora_adsb_config *cfg) {
 	    dev_alloc(&ctx->d_stats, (uint64_t) g * SORA_STAT_WORDS) != hipSuccess ||
 	    dev_alloc(&ctx->d_acc_offset, nr + 1) != hipSuccess ||
 	    dev_alloc(&ctx->d_sq_offset, g + 1) != hipSuccess ||
+	    dev_alloc(&ctx->d_export, ctx->export_cap) != hipSuccess ||
 	    dev_alloc(&ctx->d_rec_count, g) != hipSuccess ||
 	    dev_alloc(&ctx->d_sq_count, g) != hipSuccess ||
 	    dev_alloc(&ctx->d_acc_count, nr) != hipSuccess)
@@ -357,6 +365,7 @@ sora_adsb_scan(sora_adsb_ctx *ctx, const void *d_iq, size_t nbytes, int encoding
     ctx->groups = groups;
     ctx->scanned = false;
     ctx->resolved = false;
+    ctx->merged = ctx->exported = false;
 
     HIP_TRY(ctx, hipEventRecord(ctx->ev_scan_begin, ctx->stream));
     HIP_TRY(ctx, sora_launch_scan(&a, groups, ctx->stream));
@@ -366,18 +375,42 @@ sora_adsb_scan(sora_adsb_ctx *ctx, const void *d_iq, size_t nbytes, int encoding
     return SORA_OK;
 }
 
+namespace {
+
+/* first-seen merge of this scan's squitters + the export list (once per scan) */
+int
+export_first(sora_adsb_ctx *ctx) {
+    if (ctx->exported)
+	return SORA_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!ctx->merged) {
+	HIP_TRY(ctx, sora_launch_first_seen(&ctx->res, ctx->stream));
+	ctx->merged = true;
+    }
+    HIP_TRY(ctx, sora_launch_export_first(&ctx->res, ctx->d_export, ctx->export_cap,
+	    ctx->d_sq_offset, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(&ctx->h_total[0], ctx->d_sq_offset, sizeof(uint64_t),
+	    hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->h_total[0] > ctx->export_cap)
+	return fail(ctx, SORA_ERR_OVERFLOW, "%llu addresses first seen in one scan "
+		"exceed the export list (%llu)", (unsigned long long) ctx->h_total[0],
+		(unsigned long long) ctx->export_cap);
+    ctx->exported = true;
+    return SORA_OK;
+}
+
+} /* namespace */
+
 extern "C" int
 sora_adsb_squitter_count(sora_adsb_ctx *ctx, uint64_t *n) {
     if (ctx == nullptr || n == nullptr)
 	return SORA_ERR_INVALID;
     if (!ctx->scanned)
 	return fail(ctx, SORA_ERR_STATE, "no scan to count squitters of");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, sora_launch_scan_counts(ctx->d_sq_count, ctx->res.sq_cap,
-	    ctx->d_sq_offset, ctx->groups, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(&ctx->h_total[0], ctx->d_sq_offset + ctx->groups,
-	    sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    int rc = export_first(ctx);
+    if (rc != SORA_OK)
+	return rc;
     *n = ctx->h_total[0];
     return SORA_OK;
 }
@@ -388,9 +421,13 @@ sora_adsb_copy_squitters(sora_adsb_ctx *ctx, void *d_dst, size_t cap_records) {
 	return SORA_ERR_INVALID;
     if (!ctx->scanned)
 	return fail(ctx, SORA_ERR_STATE, "no scan to export squitters of");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, sora_launch_export_squitters(&ctx->res, ctx->d_sq_offset,
-	    static_cast<uint64_t *>(d_dst), cap_records, ctx->stream));
+    int rc = export_first(ctx);
+    if (rc != SORA_OK)
+	return rc;
+    const size_t n = ctx->h_total[0] < cap_records? (size_t) ctx->h_total[0] : cap_records;
+    if (n > 0)
+	HIP_TRY(ctx, hipMemcpyAsync(d_dst, ctx->d_export, n * sizeof(uint64_t),
+		hipMemcpyDeviceToDevice, ctx->stream));
     return SORA_OK;
 }
 
@@ -411,7 +448,10 @@ sora_adsb_resolve(sora_adsb_ctx *ctx) {
     if (!ctx->scanned)
 	return fail(ctx, SORA_ERR_STATE, "resolve without a scan");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, sora_launch_first_seen(&ctx->res, ctx->stream));
+    if (!ctx->merged) {
+	HIP_TRY(ctx, sora_launch_first_seen(&ctx->res, ctx->stream));
+	ctx->merged = true;
+    }
     HIP_TRY(ctx, sora_launch_filter(&ctx->res, ctx->stream));
     HIP_TRY(ctx, sora_launch_scan_counts(ctx->d_acc_count, ctx->res.acc_cap,
 	    ctx->d_acc_offset, ctx->res.regions, ctx->stream));

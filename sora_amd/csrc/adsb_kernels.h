@@ -87,9 +87,10 @@ hipError_t sora_launch_first_seen(const struct sora_resolve_args *a,
 /* same from flat global records (position << 24 | address) */
 hipError_t sora_launch_add_known(uint64_t *first_seen, uint32_t *known_bits,
 	const uint64_t *records, uint64_t n, hipStream_t stream);
-/* squitter lists -> flat global records; offsets = exclusive scan */
-hipError_t sora_launch_export_squitters(const struct sora_resolve_args *a,
-	uint64_t *scan_tmp, uint64_t *dst, uint64_t dst_cap, hipStream_t stream);
+/* per address the earliest squitter of this scan (needs first_seen) -> flat
+ * global records, unordered; *counter = how many there are (may exceed cap) */
+hipError_t sora_launch_export_first(const struct sora_resolve_args *a, uint64_t *dst,
+	uint64_t dst_cap, uint64_t *counter, hipStream_t stream);
 hipError_t sora_launch_filter(const struct sora_resolve_args *a,
 	hipStream_t stream);
 hipError_t sora_launch_scan_counts(const uint32_t *counts, uint32_t cap,

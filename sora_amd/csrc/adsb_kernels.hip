@@ -584,22 +584,31 @@ scan_counts_kernel(const uint32_t *counts, uint32_t cap, uint64_t *offsets,
 	offsets[n] = s_carry;
 }
 
-/* squitter regions -> flat records (global position << 24 | address) */
+/*
+ * What another time shard has to learn from this one: per address, the
+ * EARLIEST clean squitter of this scan -- the record whose position is the
+ * address's entry in first_seen (first_seen_kernel ran before).  A few hundred
+ * records per hour instead of every squitter.  Flat records
+ * (global position << 24 | address), unordered, counted by one atomic each.
+ */
 __global__ void
-export_squitters_kernel(sora_resolve_args a, const uint64_t *offsets,
-	uint64_t *dst, uint64_t dst_cap) {
+export_first_kernel(sora_resolve_args a, uint64_t *dst, uint64_t dst_cap,
+	unsigned long long *counter) {
     const uint32_t group = blockIdx.x;
     uint32_t n = a.sq_count[group];
     const uint64_t *sq = a.sq + (uint64_t) group * a.sq_cap;
-    const uint64_t off = offsets[group];
 
     if (n > a.sq_cap)
 	n = a.sq_cap;
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-	uint64_t r = sq[i];
-	if (off + i < dst_cap)
-	    dst[off + i] = ((a.base_position + sora_rec_pos(r)) << 24) |
-		    sora_rec_addr(r);
+	const uint64_t r = sq[i];
+	const uint64_t position = a.base_position + sora_rec_pos(r);
+	const uint32_t addr = sora_rec_addr(r);
+	if (a.first_seen[addr] == position) {
+	    const unsigned long long k = atomicAdd(counter, 1ull);
+	    if (k < dst_cap)
+		dst[k] = (position << 24) | addr;
+	}
     }
 }
 
@@ -1015,15 +1024,14 @@ sora_launch_scan_counts(const uint32_t *counts, uint32_t cap,
 }
 
 hipError_t
-sora_launch_export_squitters(const sora_resolve_args *a, uint64_t *scan_tmp,
-	uint64_t *dst, uint64_t dst_cap, hipStream_t stream) {
-    hipError_t e = sora_launch_scan_counts(a->sq_count, a->sq_cap, scan_tmp,
-	    a->groups, stream);
+sora_launch_export_first(const sora_resolve_args *a, uint64_t *dst, uint64_t dst_cap,
+	uint64_t *counter, hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(counter, 0, sizeof(uint64_t), stream);
     if (e != hipSuccess)
 	return e;
     (void) hipGetLastError();
-    hipLaunchKernelGGL(export_squitters_kernel, dim3(a->groups), dim3(256), 0,
-	    stream, *a, scan_tmp, dst, dst_cap);
+    hipLaunchKernelGGL(export_first_kernel, dim3(a->groups), dim3(256), 0, stream,
+	    *a, dst, dst_cap, reinterpret_cast<unsigned long long *>(counter));
     return hipGetLastError();
 }
 

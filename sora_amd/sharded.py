@@ -2,9 +2,10 @@
 
 One process per GPU; rank r owns the positions [r*per, (r+1)*per) of the
 capture and holds 239 halo samples behind them.  The scan needs no
-communication.  The path's one exchange: every rank's clean-squitter records
-(position << 24 | address, 8 bytes each) are all-gathered so that each rank's
-first-seen table knows the addresses earlier ranks introduced
+communication.  The path's one exchange: per address a rank saw first, its
+earliest clean squitter (position << 24 | address, 8 bytes; a few hundred
+records per hour) is all-gathered so that each rank's first-seen table knows
+the addresses earlier ranks introduced
 (`torch.distributed`: backend nccl = RCCL over xGMI on the GPUs, gloo in the
 CPU tests).  Sample data never moves.
 
@@ -71,7 +72,23 @@ class LocalDecoder:
                       n_owned=n_owned)
 
     def exchange(self):
-        self.ctx.resolve()
+        ctx, world, rank = self.ctx, self.world, self.rank
+        with self._on_stream():
+            ks = self._all_counts(ctx.squitter_count())
+            if max(ks) > self.max_records:
+                raise RuntimeError(f"{max(ks)} exchange records exceed {self.max_records}")
+            m = max(ks)
+            if m:
+                ctx.copy_squitters(self.d_sq, self.max_records)
+                ctx.synchronize()
+                dist.all_gather_into_tensor(self.d_sq_all[:world * m], self.d_sq[:m],
+                                            group=self.group)
+                if self.cuda and self.stream is None:
+                    torch.cuda.current_stream().synchronize()
+                for r in range(world):
+                    if r != rank and ks[r]:
+                        ctx.add_known(self.d_sq_all[r * m:r * m + ks[r]], ks[r])
+            ctx.resolve()
 
     def finish(self):
         self.n = self.ctx.collect_into(self.h_frames)
@@ -103,8 +120,10 @@ class ShardedDecoder:
         self.device, self.max_frames, self.group = device, int(max_frames), group
         self.stream, self.gather = stream, gather
         self.cuda = device.type == "cuda"
-        self.d_sq = torch.zeros(self.max_frames, dtype=torch.int64, device=device)
-        self.d_sq_all = torch.zeros(world * self.max_frames, dtype=torch.int64,
+        # exchange records: one per address a shard saw first, not one per squitter
+        self.max_records = min(self.max_frames, 1 << 20)
+        self.d_sq = torch.zeros(self.max_records, dtype=torch.int64, device=device)
+        self.d_sq_all = torch.zeros(world * self.max_records, dtype=torch.int64,
                                     device=device)
         self.counts = torch.zeros(world, dtype=torch.int64, device=device)
         self.d_out = torch.zeros(self.max_frames * FRAME_BYTES, dtype=torch.uint8,
@@ -208,11 +227,11 @@ class ShardedDecoder:
         ctx, world, rank = self.ctx, self.world, self.rank
         with self._on_stream():
             ks = self._all_counts(ctx.squitter_count())
-            if max(ks) > self.max_frames:
-                raise RuntimeError(f"{max(ks)} squitter records exceed max_frames")
+            if max(ks) > self.max_records:
+                raise RuntimeError(f"{max(ks)} exchange records exceed {self.max_records}")
             m = max(ks)
             if m:
-                ctx.copy_squitters(self.d_sq, self.max_frames)
+                ctx.copy_squitters(self.d_sq, self.max_records)
                 ctx.synchronize()
                 dist.all_gather_into_tensor(self.d_sq_all[:world * m], self.d_sq[:m],
                                             group=self.group)
