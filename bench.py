@@ -48,7 +48,9 @@ def parse_args():
                          "(sc16 uses the dense configs[3] traffic)")
     ap.add_argument("--inflight", type=int, default=2,
                     help="captures in flight (decoders on streams of their own); 1 = "
-                         "strictly one after the other")
+                         "strictly one after the other; 3 also moves the N>1 exchange "
+                         "under the next scan (measured slower: its small kernels queue "
+                         "behind the persistent scan kernel)")
     ap.add_argument("--gather", choices=("shm", "collective"), default="shm",
                     help="N>1: frame lists to rank 0 through a shared host segment "
                          "(every rank over its own PCIe link) or by an RCCL gather")
@@ -178,25 +180,52 @@ def main():
         scan_ms.append(d.ctx.last_scan_ms())
         return n
 
+    def mark(i):
+        ev = torch.cuda.Event()
+        ev.record(streams[i % len(decs)])
+        return ev
+
     def run(k):
-        """k steps, pipelined over the decoders; returns the last frame count."""
-        n, prev, resolved = 0, None, None
+        """k steps, pipelined over the decoders; returns the last frame count.
+
+        Kernels of different captures never share the GPU (a scan whose static
+        tile ranges compete with another capture's resolve gets stragglers):
+        events put them in the order S(i), R(i-1), S(i+1), R(i), ...  What
+        overlaps a scan is host work and copies: with two decoders the previous
+        capture's frame copy, with three also the previous capture's exchange
+        (squitter records over RCCL, N>1), whose host-side waits would otherwise
+        leave the GPU idle between a scan and its resolve."""
+        n_dec, n = len(decs), 0
+        if n_dec >= 3:
+            scanned, resolved = {}, {}
+            for i in range(k + 2):
+                if i < k:                                  # S(i) behind R(i-2)
+                    if i - 2 in resolved:
+                        streams[i % n_dec].wait_event(resolved.pop(i - 2))
+                    timed("begin", decs[i % n_dec].begin, *job)
+                    scanned[i] = mark(i)
+                j = i - 1
+                if 0 <= j < k:                             # R(j) behind S(j+1)
+                    if j + 1 in scanned:
+                        streams[j % n_dec].wait_event(scanned.pop(j + 1))
+                    timed("exchange", decs[j % n_dec].exchange)
+                    resolved[j] = mark(j)
+                if 0 <= i - 2 < k:                         # frames of capture i-2
+                    n = finish(decs[(i - 2) % n_dec])
+            return n
+        prev, resolved = None, None
         for i in range(k):
-            d = decs[i % len(decs)]
-            if len(decs) == 1 and prev is not None:
+            d = decs[i % n_dec]
+            if n_dec == 1 and prev is not None:
                 n, prev = finish(prev), None
             if resolved is not None:
-                # kernels of the two captures run one after the other (a scan that
-                # shares the CUs with another capture's resolve gets stragglers);
-                # what overlaps this scan is the previous capture's copy to the host
-                streams[i % len(decs)].wait_event(resolved)
+                streams[i % n_dec].wait_event(resolved)    # S(i) behind R(i-1)
             timed("begin", d.begin, *job)  # reset (a new capture) + scan, asynchronous
             if prev is not None:
                 n = finish(prev)
             timed("exchange", d.exchange)  # (N>1: squitter exchange) + resolve
-            if len(decs) > 1:
-                resolved = torch.cuda.Event()
-                resolved.record(streams[i % len(decs)])
+            if n_dec > 1:
+                resolved = mark(i)
             prev = d
         if prev is not None:
             n = finish(prev)

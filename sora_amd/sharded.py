@@ -72,23 +72,7 @@ class LocalDecoder:
                       n_owned=n_owned)
 
     def exchange(self):
-        ctx, world, rank = self.ctx, self.world, self.rank
-        with self._on_stream():
-            ks = self._all_counts(ctx.squitter_count())
-            if max(ks) > self.max_records:
-                raise RuntimeError(f"{max(ks)} exchange records exceed {self.max_records}")
-            m = max(ks)
-            if m:
-                ctx.copy_squitters(self.d_sq, self.max_records)
-                ctx.synchronize()
-                dist.all_gather_into_tensor(self.d_sq_all[:world * m], self.d_sq[:m],
-                                            group=self.group)
-                if self.cuda and self.stream is None:
-                    torch.cuda.current_stream().synchronize()
-                for r in range(world):
-                    if r != rank and ks[r]:
-                        ctx.add_known(self.d_sq_all[r * m:r * m + ks[r]], ks[r])
-            ctx.resolve()
+        self.ctx.resolve()
 
     def finish(self):
         self.n = self.ctx.collect_into(self.h_frames)

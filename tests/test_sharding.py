@@ -147,3 +147,21 @@ def test_two_ranks_equal_one(tmp_path, gather):
     from sora_amd import bits_to_string
     assert [bits_to_string(f["bits"]) for f in got] == [c["bits"] for c in want]
     assert [float(f["amplitude_56"]) for f in got] == [c["amplitude_56"] for c in want]
+
+
+def test_local_decoder_phases():
+    """LocalDecoder is ShardedDecoder's three phases with no exchange: begin scans,
+    exchange resolves, finish collects (bench.py runs N=1 through it)."""
+    from sora_amd.sharded import LocalDecoder
+    p = synth.default_params(2, n_samples=60000, mean_gap=900, n_icao=3, seed=3)
+    raw = synth.fill_host(p.n_samples, p.encoding, p.seed, synth.make_frames(p)).tobytes()
+    ctx = OracleContext()
+    ctx.collect_into = lambda out: (out.__setitem__(slice(0, len(ctx.frames)), ctx.frames),
+                                    len(ctx.frames))[1]
+    dec = LocalDecoder(ctx, 5000, pin=False)
+    shard = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
+    for _ in range(2):
+        n = dec.step(shard, len(raw), ob.ENC_UC8, 0, p.n_samples)
+    want = [c for c in ob.scan(raw) if c["accepted"]]
+    assert n == len(want) > 10
+    assert [int(f["position"]) for f in dec.frames()] == [c["position"] for c in want]
