@@ -149,3 +149,67 @@ def test_sora_correction_env_matches_oracle():
     assert run_sora(args, raw, {"SORA_ADSB_CORRECT": "1"}) == fixed
     assert run_sora(["-d", "--adsb-from-raw"], raw, {"SORA_ADSB_CORRECT": "1"}) == \
         ob.main_loop_text(raw, 0x11, correct=True)
+
+
+def test_radio_file_read_conversions(tmp_path):
+    """Row a14 (radio-file.c:96-152): every encoding widens to double complex
+    exactly ((b-128)/128, b/128, s/32768; u8 and s16 real), whole items only, 0
+    at the end of the file.  Expected values computed here in float64 (the
+    arithmetic is exact in double)."""
+    import numpy as np
+    L = C.CDLL(HOST_SO)
+
+    class Methods(C.Structure):
+        pass
+
+    class Radio(C.Structure):
+        _fields_ = [("m", C.POINTER(Methods))]
+
+    RP = C.POINTER(Radio)
+    Methods._fields_ = [
+        ("set_frequency", C.CFUNCTYPE(C.c_int, RP, C.c_uint64)),
+        ("get_frequency", C.CFUNCTYPE(C.c_int, RP, C.POINTER(C.c_uint64))),
+        ("set_sample_rate", C.CFUNCTYPE(C.c_int, RP, C.c_ulong)),
+        ("get_sample_rate", C.CFUNCTYPE(C.c_int, RP, C.POINTER(C.c_ulong))),
+        ("read", C.CFUNCTYPE(C.c_ssize_t, RP, C.c_void_p, C.c_size_t)),
+        ("get_file_position", C.CFUNCTYPE(C.c_long, RP)),
+        ("close", C.CFUNCTYPE(None, RP)),
+    ]
+    L.radio_file_open.restype = RP
+    L.radio_file_open.argtypes = [C.c_char_p, C.c_int]
+    rng = np.random.default_rng(7)
+    raw = rng.integers(0, 256, size=4 * 1000 + 3, dtype=np.uint8)    # ragged tail
+    path = tmp_path / "x.bin"
+    path.write_bytes(raw.tobytes())
+    u8 = raw.astype(np.float64)
+    s8 = raw.view(np.int8).astype(np.float64)
+    s16 = raw[:len(raw) // 2 * 2].view("<i2").astype(np.float64)
+    want = {
+        1: ((u8[0::2][:2001] - 128) / 128) + 1j * ((u8[1::2][:2001] - 128) / 128),   # uc8
+        3: (s8[0::2][:2001] / 128) + 1j * (s8[1::2][:2001] / 128),                   # sc8
+        2: (s16[0::2][:1000] / 32768) + 1j * (s16[1::2][:1000] / 32768),             # sc16
+        32: ((u8 - 128) / 128) + 0j,                                                 # u8
+        33: (s16 / 32768) + 0j,                                                      # s16
+    }
+    for enc, expect in want.items():
+        r = L.radio_file_open(str(path).encode(), enc)
+        assert r
+        m = r.contents.m.contents
+        got = []
+        buf = np.empty(300, dtype=np.complex128)                 # several partial reads
+        while True:
+            k = m.read(r, buf.ctypes.data, buf.size)
+            if k <= 0:
+                break
+            got.append(buf[:k].copy())
+        rate = C.c_ulong()
+        assert m.get_sample_rate(r, C.byref(rate)) == 0 and rate.value == 1   # radio-file.c:51
+        m.close(r)
+        got = np.concatenate(got)
+        assert got.shape == expect.shape, enc
+        assert np.array_equal(got.view(np.float64), expect.astype(np.complex128).view(np.float64))
+    # an unknown encoding opens (main.c:229-230 only warns) and reads nothing
+    r = L.radio_file_open(str(path).encode(), 0)
+    if r:
+        assert r.contents.m.contents.read(r, buf.ctypes.data, 10) == 0
+        r.contents.m.contents.close(r)
