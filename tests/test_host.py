@@ -191,6 +191,15 @@ def test_radio_file_read_conversions(tmp_path):
         32: ((u8 - 128) / 128) + 0j,                                                 # u8
         33: (s16 / 32768) + 0j,                                                      # s16
     }
+    # the same file is a golden fixture: what the COMPILED REFERENCE's
+    # radio->m->read() returned for it (oracle/ref_radio_file_driver.c,
+    # tools/make_golden.py) must equal the float64 formulas above
+    with open(os.path.join(GOLDEN, "radio_file.bin"), "rb") as fh:
+        assert fh.read() == raw.tobytes()
+    for enc, expect in want.items():
+        with open(os.path.join(GOLDEN, f"radio_file.enc{enc}.txt")) as fh:
+            ref = np.array([[float.fromhex(x) for x in line.split()] for line in fh])
+        assert np.array_equal(ref[:, 0], expect.real) and np.array_equal(ref[:, 1], expect.imag)
     for enc, expect in want.items():
         r = L.radio_file_open(str(path).encode(), enc)
         assert r

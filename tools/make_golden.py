@@ -103,6 +103,24 @@ def main():
         print(name, index[name])
     with open(os.path.join(GOLDEN, "INDEX.json"), "w") as fh:
         json.dump(index, fh, indent=1, sort_keys=True)
+    radio_file_fixture()
+
+
+def radio_file_fixture():
+    """Row a14: what the reference's radio->m->read() returns for one ragged file
+    under every encoding of radio-file.h:6-12 (hex floats, one sample a line)."""
+    import subprocess
+    rng = np.random.default_rng(7)
+    raw = rng.integers(0, 256, size=4 * 1000 + 3, dtype=np.uint8).tobytes()
+    path = os.path.join(GOLDEN, "radio_file.bin")
+    with open(path, "wb") as fh:
+        fh.write(raw)
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_radio_file")
+    for enc in (1, 2, 3, 32, 33):
+        p = subprocess.run([exe, path, str(enc), "300"], capture_output=True, check=True)
+        with open(os.path.join(GOLDEN, f"radio_file.enc{enc}.txt"), "wb") as fh:
+            fh.write(p.stdout)
+        print("radio_file enc", enc, p.stdout.count(b"\n"), "samples")
 
 
 if __name__ == "__main__":
