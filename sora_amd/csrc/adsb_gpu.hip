@@ -244,7 +244,7 @@ sora_adsb_create(sora_adsb_ctx **out, int device, const sora_adsb_config *cfg) {
     /* the scan kernels run sora_scan_groups_per_cu() workgroups on every CU
      * (what their LDS lets a CU hold): at most 4 */
     ctx->cus = prop.multiProcessorCount > 0? (uint32_t) prop.multiProcessorCount : 1;
-    ctx->max_groups = ctx->cus * 6;
+    ctx->max_groups = ctx->cus * 8;
     ctx->max_regions = sora_filter_regions(ctx->max_groups);
 
     const uint64_t n = cfg->max_chunk_samples;

@@ -49,7 +49,11 @@ template <> struct tile_geom<false> {		/* uc8, sc8: 16-bit magnitudes */
     static constexpr int m_dwords = SORA_M_DWORDS;
     static constexpr int m_tail = 4;		/* zeroed dwords behind the last lane */
     static constexpr int words = SORA_WORDS;
+#ifdef SORA_WAVES_PER_SIMD
+    static constexpr int waves_per_simd = SORA_WAVES_PER_SIMD;
+#else
     static constexpr int waves_per_simd = 6;	/* 24 waves per CU */
+#endif
 };
 template <> struct tile_geom<true> {		/* sc16: 32-bit magnitudes */
     static constexpr int threads = SORA16_TILE_THREADS;
@@ -963,7 +967,11 @@ sora_scan_tiles(uint64_t n_scan, int encoding) {
 uint32_t
 sora_scan_groups_per_cu(int encoding) {
     /* workgroups of one CU: bounded by LDS (45 KB and 39 KB per workgroup) */
+#ifdef SORA_GROUPS_PER_CU
+    return encoding == SORA_ENC_SC16? 4 : SORA_GROUPS_PER_CU;
+#else
     return encoding == SORA_ENC_SC16? 4 : 3 * 512 / SORA_TILE_THREADS;
+#endif
 }
 
 hipError_t
