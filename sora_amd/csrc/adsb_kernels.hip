@@ -325,13 +325,15 @@ adsb_scan_kernel(sora_scan_args a) {
 	/* ---- phase 3: predicate words, ordered queue of hits ---- */
 	/* the CRC tables for phase 4: fetched now, stored once the scan is done */
 	constexpr int kTabs = (kCrcCopies + kFixCopies + kThreads - 1) / kThreads;
+	/* pieces every lane copies need no test */
+#define SORA_ALWAYS(c) (((c) + 1) * kThreads <= kCrcCopies)
 	const uint32_t copies = a.correct? kCrcCopies + kFixCopies : kCrcCopies;
 	u32x4 tab[kTabs];
 	{
 	    const u32x4 *src = reinterpret_cast<const u32x4 *>(g_crc_slices.w);
 #pragma unroll
 	    for (int c = 0; c < kTabs; c++)
-		if ((c + 1) * kThreads <= kCrcCopies || c * kThreads + tid < copies)
+		if (SORA_ALWAYS(c) || c * kThreads + tid < copies)
 		    tab[c] = src[c * kThreads + tid];
 	}
 	uint32_t pe, po;
@@ -360,7 +362,7 @@ adsb_scan_kernel(sora_scan_args a) {
 	    s_part[wave] = incl;
 #pragma unroll
 	for (int c = 0; c < kTabs; c++)
-	    if ((c + 1) * kThreads <= kCrcCopies || c * kThreads + tid < copies)
+	    if (SORA_ALWAYS(c) || c * kThreads + tid < copies)
 		*reinterpret_cast<u32x4 *>(&s_crc[4 * c * kThreads + 4 * t]) = tab[c];
 	if (tid == 0)
 	    s_sq_count = 0;
