@@ -47,7 +47,7 @@ template <> struct tile_geom<false> {		/* uc8, sc8: 16-bit magnitudes */
     static constexpr int bytes_per_sample = 2;
     static constexpr int lane_stride = SORA_LANE_STRIDE;
     static constexpr int m_dwords = SORA_M_DWORDS;
-    static constexpr int m_tail = 4;		/* zeroed dwords behind the last lane */
+    static constexpr int m_tail = 16;		/* zeroed dwords behind the last lane */
     static constexpr int words = SORA_WORDS;
 #ifdef SORA_WAVES_PER_SIMD
     static constexpr int waves_per_simd = SORA_WAVES_PER_SIMD;
@@ -180,8 +180,14 @@ adsb_scan_kernel(sora_scan_args a) {
     constexpr int kTilePos = G::tile_pos;
     constexpr int kQueueMax = kTilePos / 2;		/* p and p+1 never both hit */
     constexpr int kCrcTableDword = (kQueueMax / 2 + 63) & ~63;	/* past the queue */
-    /* the buffer holds M in phases 1-2, then the queue and the tables */
-    constexpr int kAfterM = kCrcTableDword + SORA_CRC_TABLE_WORDS + SORA_FIX_TABLE_WORDS;
+    /* The buffer holds M in phases 1-2, then the queue.  The sliced CRC tables
+     * (and the correction lookup) follow it there in the sc16 kernel, copied in
+     * again every tile; the 8-bit kernel, whose swizzled M needs no padding,
+     * has room to keep them in LDS for good (a copy per tile was 5 % of its
+     * time). */
+    constexpr bool kTablesStay = !kWide;
+    constexpr int kTabWords = SORA_CRC_TABLE_WORDS + SORA_FIX_TABLE_WORDS;
+    constexpr int kAfterM = kCrcTableDword + (kTablesStay? 0 : kTabWords);
     constexpr int kBufDwords = G::m_dwords > kAfterM? G::m_dwords : kAfterM;
 
     __shared__ __attribute__((aligned(16))) uint32_t s_m[kBufDwords];
@@ -189,6 +195,7 @@ adsb_scan_kernel(sora_scan_args a) {
     __shared__ __attribute__((aligned(4))) uint16_t s_bits[4][2 * G::words];
     uint16_t *const s_nue = s_bits[0], *const s_nuo = s_bits[1];
     uint16_t *const s_de = s_bits[2], *const s_do = s_bits[3];
+    __shared__ __attribute__((aligned(16))) uint32_t s_tab[kTablesStay? kTabWords : 4];
     __shared__ uint32_t s_part[kWaves];
     __shared__ uint32_t s_sq_count;
 
@@ -207,7 +214,13 @@ adsb_scan_kernel(sora_scan_args a) {
     uint32_t st_cand = 0, st_sq = 0, st_dirty = 0, st_fixed = 0;
 
     uint16_t *s_queue = reinterpret_cast<uint16_t *>(s_m);
-    uint32_t *s_crc = s_m + kCrcTableDword;
+    uint32_t *s_crc = kTablesStay? s_tab : s_m + kCrcTableDword;
+    if constexpr (kTablesStay) {
+	const u32x4 *src = reinterpret_cast<const u32x4 *>(g_crc_slices.w);
+	for (uint32_t c = tid; c < (uint32_t) kTabWords / 4; c += kThreads)
+	    *reinterpret_cast<u32x4 *>(&s_tab[4 * c]) = src[c];
+	/* visible to every wave behind the first tile's barriers */
+    }
     STAMP_DECL;
     const uint32_t *w_nue = reinterpret_cast<const uint32_t *>(s_nue);
     const uint32_t *w_nuo = reinterpret_cast<const uint32_t *>(s_nuo);
@@ -261,8 +274,10 @@ adsb_scan_kernel(sora_scan_args a) {
 		    at = r * (kThreads * 4 / 32) * G::lane_stride + 4 * t + 4 * (t >> 3);
 		} else {
 		    sora_mag2_pack8x4(raw, flip, mm);	/* one dword per pair */
-		    /* 16 + 4 dwords per lane */
-		    at = r * (kThreads * 4 / 16) * G::lane_stride + 4 * t + 4 * (t >> 2);
+		    /* chunk t & 3 of lane r * (kThreads / 4) + (t >> 2), swizzled
+		     * (kThreads / 4 is a multiple of 16: r adds a constant) */
+		    at = r * (kThreads * 4 / 16) * G::lane_stride +
+			    sora_m_chunk(t >> 2, t & 3);
 		}
 		const u32x4 m = {mm[0], mm[1], mm[2], mm[3]};
 		*reinterpret_cast<u32x4 *>(&s_m[at]) = m;
@@ -289,17 +304,15 @@ adsb_scan_kernel(sora_scan_args a) {
 	    }
 	    sora_lane_compare32(M, &up, &down, &cc);
 	} else {
-	    uint32_t P[SORA_LANE_STRIDE];
+	    uint32_t P[SORA_LANE_PAIRS + 4];
 #pragma unroll
 	    for (int i = 0; i < 4; i++) {
-		u32x4 q4 = *reinterpret_cast<const u32x4 *>(
-			&s_m[t * SORA_LANE_STRIDE + 4 * i]);
+		u32x4 q4 = *reinterpret_cast<const u32x4 *>(&s_m[sora_m_chunk(t, i)]);
 		P[4 * i] = q4[0]; P[4 * i + 1] = q4[1];
 		P[4 * i + 2] = q4[2]; P[4 * i + 3] = q4[3];
 	    }
 	    {
-		u32x4 q4 = *reinterpret_cast<const u32x4 *>(
-			&s_m[t * SORA_LANE_STRIDE + SORA_LANE_STRIDE]);
+		u32x4 q4 = *reinterpret_cast<const u32x4 *>(&s_m[sora_m_chunk(t + 1, 0)]);
 		P[16] = q4[0]; P[17] = q4[1]; P[18] = q4[2]; P[19] = q4[3];
 	    }
 	    sora_lane_compare(P, &up, &down, &cc);
@@ -324,12 +337,12 @@ adsb_scan_kernel(sora_scan_args a) {
 
 	/* ---- phase 3: predicate words, ordered queue of hits ---- */
 	/* the CRC tables for phase 4: fetched now, stored once the scan is done */
-	constexpr int kTabs = (kCrcCopies + kFixCopies + kThreads - 1) / kThreads;
+	constexpr int kTabs = kTablesStay? 0 : (kCrcCopies + kFixCopies + kThreads - 1) / kThreads;
 	/* pieces every lane copies need no test */
 #define SORA_ALWAYS(c) (((c) + 1) * kThreads <= kCrcCopies)
 	const uint32_t copies = a.correct? kCrcCopies + kFixCopies : kCrcCopies;
-	u32x4 tab[kTabs];
-	{
+	u32x4 tab[kTabs > 0? kTabs : 1];
+	if constexpr (!kTablesStay) {
 	    const u32x4 *src = reinterpret_cast<const u32x4 *>(g_crc_slices.w);
 #pragma unroll
 	    for (int c = 0; c < kTabs; c++)
@@ -360,10 +373,12 @@ adsb_scan_kernel(sora_scan_args a) {
 	const uint32_t incl = wave_inclusive_scan(cnt);
 	if (lane == 63)
 	    s_part[wave] = incl;
+	if constexpr (!kTablesStay) {
 #pragma unroll
-	for (int c = 0; c < kTabs; c++)
-	    if (SORA_ALWAYS(c) || c * kThreads + tid < copies)
-		*reinterpret_cast<u32x4 *>(&s_crc[4 * c * kThreads + 4 * t]) = tab[c];
+	    for (int c = 0; c < kTabs; c++)
+		if (SORA_ALWAYS(c) || c * kThreads + tid < copies)
+		    *reinterpret_cast<u32x4 *>(&s_crc[4 * c * kThreads + 4 * t]) = tab[c];
+	}
 	if (tid == 0)
 	    s_sq_count = 0;
 	lds_barrier();

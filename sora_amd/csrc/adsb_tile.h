@@ -43,11 +43,16 @@
 #define SORA_OWN_LANES		(SORA_TILE_THREADS - 8)	/* lanes whose positions a tile owns */
 #define SORA_TILE_POS		(SORA_OWN_LANES * SORA_LANE_POS)	/* 16128 */
 #define SORA_TILE_SAMPLES	(SORA_TILE_THREADS * SORA_LANE_POS)	/* 16384 */
-/* M in LDS: lane g's 16 dwords start at dword 20*g (4 dwords of padding keep
- * both the 16-byte stores of the load phase and the 16-byte reads of the
- * compare phase bank-conflict free: 20 = 4*5, 5 odd) */
-#define SORA_LANE_STRIDE	20
-#define SORA_M_DWORDS		(SORA_TILE_THREADS * SORA_LANE_STRIDE + 4)
+/* M in LDS: lane g's 16 dwords are the 64 bytes at dword 16*g, their four
+ * 16-byte chunks permuted by an XOR swizzle: chunk i of lane g sits at chunk
+ * i ^ ((g >> 2) & 3).  No padding (32 KB for a tile), and both the 16-byte
+ * stores of the load phase (8 consecutive lanes of a store fill two whole
+ * lanes' runs) and the 16-byte reads of the compare phase stay bank-conflict
+ * free: ds_read_b128 serves lanes {0-3,12-15,20-27}, {4-11,16-19,28-31}, ...
+ * together, and within such a group the lanes with equal g mod 4 (the ones
+ * that share a 64-bank column) have four different (g >> 2) & 3. */
+#define SORA_LANE_STRIDE	16
+#define SORA_M_DWORDS		(SORA_TILE_THREADS * SORA_LANE_STRIDE + 16)
 /* bit arrays: one 16-bit half word per lane, +1 word of lookahead; as 32-bit
  * words, MSB first: lane 2w is the top half of word w */
 #define SORA_WORDS		(SORA_TILE_THREADS / 2 + 1)
@@ -81,6 +86,12 @@ sora_rec_make(uint64_t kind, uint64_t pos, uint32_t addr) {
 SORA_HD uint64_t sora_rec_pos(uint64_t r) { return (r >> 24) & 0xfffffffffull; }
 SORA_HD uint32_t sora_rec_addr(uint64_t r) { return (uint32_t) r & 0xffffffu; }
 SORA_HD uint32_t sora_rec_kind(uint64_t r) { return (uint32_t) (r >> 60); }
+
+/* dword index of chunk i (0..3) of lane g's run in the swizzled M layout */
+SORA_HD uint32_t
+sora_m_chunk(uint32_t g, uint32_t i) {
+    return SORA_LANE_STRIDE * g + 4 * (i ^ ((g >> 2) & 3));
+}
 
 /* ---- a1: magnitude of the two samples held in one dword of uc8/sc8 IQ ---- */
 

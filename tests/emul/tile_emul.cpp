@@ -51,19 +51,21 @@ emul_scan8(const uint8_t *iq, uint64_t n_samples, uint64_t n_scan, int encoding,
 				b[c] = iq[byte + c];
 			v = b[0] | (b[1] << 8) | (b[2] << 16) | ((uint32_t) b[3] << 24);
 		    }
-		    s_m[pair + 4 * (pair >> 4) + k] = sora_mag2_pack8(v, flip);
+		    /* pair = 16 * lane + 4 * chunk: the kernel's swizzled store */
+		    s_m[sora_m_chunk(pair >> 4, (pair >> 2) & 3) + k] =
+			    sora_mag2_pack8(v, flip);
 		}
 	    }
-	for (int k = 0; k < 4; k++)
+	for (int k = 0; k < 16; k++)
 	    s_m[SORA_TILE_THREADS * SORA_LANE_STRIDE + k] = 0;
 
 	/* phase 2 */
 	for (uint32_t tid = 0; tid < SORA_TILE_THREADS; tid++) {
-	    uint32_t P[SORA_LANE_STRIDE], up, down, cc;
+	    uint32_t P[SORA_LANE_PAIRS + 4], up, down, cc;
 	    for (int i = 0; i < SORA_LANE_PAIRS; i++)
-		P[i] = s_m[tid * SORA_LANE_STRIDE + i];
+		P[i] = s_m[sora_m_chunk(tid, i >> 2) + (i & 3)];
 	    for (int i = 0; i < 4; i++)
-		P[SORA_LANE_PAIRS + i] = s_m[(tid + 1) * SORA_LANE_STRIDE + i];
+		P[SORA_LANE_PAIRS + i] = s_m[sora_m_chunk(tid + 1, 0) + i];
 	    sora_lane_compare(P, &up, &down, &cc);
 	    s_nue[tid ^ 1] = (uint16_t) (~up & 0xffffu);
 	    s_nuo[tid ^ 1] = (uint16_t) ((~up) >> 16);
