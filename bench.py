@@ -12,7 +12,7 @@ is BASELINE.json configs[1]: a 1-hour 2 MS/s uc8 capture (7.2 G samples,
 14.4 GB) with DF17/DF11 at mixed SNR.  For N>1 every rank holds one such
 1-hour shard of an N-hour capture (weak scaling), 239 halo samples behind it.
 
-    python bench.py --gpus 1 --steps 10 --warmup 2
+    python bench.py --gpus 1 --steps 30 --warmup 5
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 """
 import argparse
@@ -36,8 +36,8 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec peak
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--samples", type=float, default=7.2e9,
                     help="samples per GPU (default: 1 hour at 2 MS/s)")
     ap.add_argument("--cpu-samples", type=float, default=120e6,
