@@ -196,8 +196,15 @@ adsb_scan_kernel(sora_scan_args a) {
     uint16_t *const s_nue = s_bits[0], *const s_nuo = s_bits[1];
     uint16_t *const s_de = s_bits[2], *const s_do = s_bits[3];
     __shared__ __attribute__((aligned(16))) uint32_t s_tab[kTablesStay? kTabWords : 4];
+    /* the hits of a tile, in position order.  They normally fit this small
+     * queue, and then nothing of phase 4 lives in the M buffer: a wave that is
+     * done with its candidates goes straight on to the next tile's loads and
+     * magnitudes.  A tile with more hits queues them in the M buffer instead
+     * and pays a barrier before that buffer is filled again. */
+    constexpr int kSmallQueue = kTablesStay? 1536 : 1;
+    __shared__ uint16_t s_small_queue[kSmallQueue];
     __shared__ uint32_t s_part[kWaves];
-    __shared__ uint32_t s_sq_count;
+    __shared__ uint32_t s_sq_total;	/* clean squitters so far, all tiles */
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63, wave = tid >> 6;
@@ -210,10 +217,12 @@ adsb_scan_kernel(sora_scan_args a) {
 
     uint64_t *rec_out = a.rec + (uint64_t) group * a.rec_cap;
     uint64_t *sq_out = a.sq + (uint64_t) group * a.sq_cap;
-    uint32_t n_rec = 0, n_sq = 0;		/* workgroup-uniform */
+    uint32_t n_rec = 0;			/* workgroup-uniform */
+    if (tid == 0)
+	s_sq_total = 0;			/* visible behind the first tile's barriers */
     uint32_t st_cand = 0, st_sq = 0, st_dirty = 0, st_fixed = 0;
 
-    uint16_t *s_queue = reinterpret_cast<uint16_t *>(s_m);
+    uint16_t *const s_big_queue = reinterpret_cast<uint16_t *>(s_m);
     uint32_t *s_crc = kTablesStay? s_tab : s_m + kCrcTableDword;
     if constexpr (kTablesStay) {
 	const u32x4 *src = reinterpret_cast<const u32x4 *>(g_crc_slices.w);
@@ -379,8 +388,6 @@ adsb_scan_kernel(sora_scan_args a) {
 		if (SORA_ALWAYS(c) || c * kThreads + tid < copies)
 		    *reinterpret_cast<u32x4 *>(&s_crc[4 * c * kThreads + 4 * t]) = tab[c];
 	}
-	if (tid == 0)
-	    s_sq_count = 0;
 	lds_barrier();
 	uint32_t total = 0, off = incl - cnt;
 #pragma unroll
@@ -390,6 +397,8 @@ adsb_scan_kernel(sora_scan_args a) {
 		off += part;
 	    total += part;
 	}
+	const bool big = !kTablesStay || total > (uint32_t) kSmallQueue;	/* uniform */
+	uint16_t *const s_queue = big? s_big_queue : s_small_queue;
 	{
 	    uint32_t both = pe | po;
 	    while (both != 0) {
@@ -445,7 +454,7 @@ adsb_scan_kernel(sora_scan_args a) {
 		if (idx < a.rec_cap)
 		    rec_out[idx] = record;
 		if (kind == SORA_REC_KIND_SQUITTER || kind == SORA_REC_KIND_CORRECTED) {
-		    const uint32_t k = n_sq + atomicAdd(&s_sq_count, 1u);
+		    const uint32_t k = atomicAdd(&s_sq_total, 1u);
 		    if (k < a.sq_cap)
 			sq_out[k] = record;
 		}
@@ -457,18 +466,19 @@ adsb_scan_kernel(sora_scan_args a) {
 	    }
 	}
 	n_rec += total;
-	lds_barrier();
-	n_sq += s_sq_count;
-	/* every lane has passed a barrier after its last read of the queue,
-	 * the CRC tables and the NU arrays, so the next tile may refill them;
-	 * s_sq_count is rewritten only behind the next tile's barriers */
+	/* The next tile refills only the M buffer before its first barrier, and
+	 * a wave passes that barrier after its last read of the queue, the
+	 * tables and the NU arrays: no barrier here unless the queue is in M. */
+	if (big)
+	    lds_barrier();
 	STAMP(6);			/* candidates: extract, CRC, records */
     }
 
     /* per-workgroup results */
+    lds_barrier();			/* the last tile's squitter appends */
     if (tid == 0) {
 	a.rec_count[group] = n_rec;
-	a.sq_count[group] = n_sq;
+	a.sq_count[group] = s_sq_total;
     }
     /* statistics: st_cand is workgroup-uniform, the others wave-uniform */
     {

@@ -109,3 +109,16 @@ def test_emulator_sc16_frames_across_tile_edges(emulator):
     check_against_oracle(emul_records16(emulator, raw), cands)
     cands = [c for c in cands if c["position"] < 3 * T + 100]
     check_against_oracle(emul_records16(emulator, raw, n_scan=3 * T + 100), cands)
+
+
+def test_emulator_dense_hits(emulator):
+    """A hit at every tenth position (see tests/test_gpu_parity.py): many hits
+    per lane, in order."""
+    v = np.array([9, 1, 8, 1, 2, 2, 2, 5, 1, 3], dtype=np.int64)
+    n = 2 * 16128 + 500
+    iq = np.full(2 * n, 128, dtype=np.uint8)
+    iq[0::2] = 128 + 10 * v[np.arange(n) % 10]
+    raw = iq.tobytes()
+    cands = ob.scan(raw)
+    assert len(cands) > 3000
+    check_against_oracle(emul_records(emulator, raw), cands)

@@ -515,3 +515,26 @@ def test_config2_full_size_properties():
         parts.append(ctx.collect())
         ctx.close()
     assert np.concatenate(parts).tobytes() == a.tobytes()
+
+
+def dense_candidates(n):
+    """A period-10 magnitude pattern with a preamble hit at every tenth position:
+    1613 candidates per 16128-position tile, more than the scan kernel's small
+    hit queue (1536) holds."""
+    v = np.array([9, 1, 8, 1, 2, 2, 2, 5, 1, 3], dtype=np.int64)
+    iq = np.full(2 * n, 128, dtype=np.uint8)
+    iq[0::2] = 128 + 10 * v[np.arange(n) % 10]
+    return iq.tobytes()
+
+
+def test_more_hits_than_the_small_queue():
+    raw = dense_candidates(3 * 16128 + 1000)
+    want = ob.scan(raw)
+    assert len(want) > 3 * 1600
+    got, counts = gpu_frames(raw)
+    assert_same_frames(got, want)
+    assert counts["candidates"] == len(want)
+    # and mixed with a sparse tail: tiles switch between the two queues
+    raw2 = raw + np.random.default_rng(4).integers(0, 256, 2 * 40000, dtype=np.uint8).tobytes()
+    got, _ = gpu_frames(raw2)
+    assert_same_frames(got, ob.scan(raw2))
