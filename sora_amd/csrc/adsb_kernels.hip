@@ -203,7 +203,10 @@ adsb_scan_kernel(sora_scan_args a) {
      * and pays a barrier before that buffer is filled again. */
     constexpr int kSmallQueue = kTablesStay? 1536 : 1;
     __shared__ uint16_t s_small_queue[kSmallQueue];
-    __shared__ uint32_t s_part[kWaves];
+    /* s_cum[w]: hits of the waves before wave w; s_cum[kWaves]: of the tile.
+     * Zeroed in phase 1, added to by every wave (one LDS atomic instruction
+     * whose lanes are the later waves), read behind the barrier. */
+    __shared__ uint32_t s_cum[kWaves + 1];
     __shared__ uint32_t s_sq_total;	/* clean squitters so far, all tiles */
 
     const uint32_t tid = threadIdx.x;
@@ -293,6 +296,8 @@ adsb_scan_kernel(sora_scan_args a) {
 	    }
 	    if (tid < G::m_tail)
 		s_m[kThreads * G::lane_stride + tid] = 0;
+	    if (tid <= kWaves)
+		s_cum[tid] = 0;
 	}
 	STAMP_WAIT_LDS();
 	STAMP(1);			/* magnitudes + LDS stores */
@@ -380,8 +385,11 @@ adsb_scan_kernel(sora_scan_args a) {
 	const uint32_t cnt = __popc(pe | po);	/* a pair never hits on both
 						 * parities: D[2j] & U[2j+1] vs D[2j+1] */
 	const uint32_t incl = wave_inclusive_scan(cnt);
-	if (lane == 63)
-	    s_part[wave] = incl;
+	{
+	    const uint32_t wave_hits = (uint32_t) __builtin_amdgcn_readlane((int) incl, 63);
+	    if (lane > wave && lane <= (uint32_t) kWaves)
+		atomicAdd(&s_cum[lane], wave_hits);
+	}
 	if constexpr (!kTablesStay) {
 #pragma unroll
 	    for (int c = 0; c < kTabs; c++)
@@ -389,14 +397,8 @@ adsb_scan_kernel(sora_scan_args a) {
 		    *reinterpret_cast<u32x4 *>(&s_crc[4 * c * kThreads + 4 * t]) = tab[c];
 	}
 	lds_barrier();
-	uint32_t total = 0, off = incl - cnt;
-#pragma unroll
-	for (int w = 0; w < kWaves; w++) {
-	    uint32_t part = s_part[w];
-	    if ((uint32_t) w < wave)
-		off += part;
-	    total += part;
-	}
+	const uint32_t total = s_cum[kWaves];
+	uint32_t off = s_cum[wave] + incl - cnt;
 	const bool big = !kTablesStay || total > (uint32_t) kSmallQueue;	/* uniform */
 	uint16_t *const s_queue = big? s_big_queue : s_small_queue;
 	{
