@@ -780,135 +780,198 @@ magnitude_f32(const uint8_t *iq, uint64_t i, int encoding) {
     return (float) (vi * vi + vq * vq) * (1.0f / 16384.0f);
 }
 
-/* the 4 magnitudes a lane needs of one frame: samples s+2*lane(+1), s+128+2*lane(+1) */
-struct frame_mags {
-    float a0, a1, b0, b1;
-};
-
-/* straight-line variant of magnitude_f32 for the finalize kernel: the encoding
- * class is a template parameter, uc8 against sc8 is the xor mask, so that the
- * compiler can issue the loads of several frames back to back */
-template <bool kWide> __device__ __forceinline__ float
-frame_sample(const uint8_t *iq, uint64_t i, uint32_t flip16) {
-    if constexpr (kWide) {
-	const uint32_t w = reinterpret_cast<const uint32_t *>(iq)[i];
-	return __uint_as_float(sora_mag_sc16(w)) * (1.0f / 1073741824.0f);
-    } else {
-	const uint32_t w = reinterpret_cast<const uint16_t *>(iq)[i] ^ flip16;
-	const int vi = (int8_t) (w & 0xff), vq = (int8_t) (w >> 8);
-	return (float) (vi * vi + vq * vq) * (1.0f / 16384.0f);
-    }
-}
-
-template <bool kWide> __device__ __forceinline__ frame_mags
-load_frame_mags(const uint8_t *iq, uint64_t p, uint32_t lane, uint32_t flip16) {
-    frame_mags m;
-    const uint64_t s = p + 16;
-    /* lanes 48..63 have no second pair: they re-read their first one */
-    const uint64_t t = lane < 48? s + 128 : s;
-    m.a0 = frame_sample<kWide>(iq, s + 2 * lane, flip16);
-    m.a1 = frame_sample<kWide>(iq, s + 2 * lane + 1, flip16);
-    m.b0 = frame_sample<kWide>(iq, t + 2 * lane, flip16);
-    m.b1 = frame_sample<kWide>(iq, t + 2 * lane + 1, flip16);
-    return m;
-}
-
 /*
- * Re-slices every accepted position from the raw samples in HBM, one wave
- * per frame: the independent second implementation of the slicer
- * (plane-iq.c:58-86) and of the CRC (plane.c:373-385), and the only place
- * amplitudes are computed (only accepted frames need them).
+ * finalize: re-slices every accepted position from the raw samples in HBM: the
+ * independent second implementation of the slicer (plane-iq.c:58-86) and of
+ * the CRC (plane.c:373-385), and the only place amplitudes are computed (only
+ * accepted frames need them).
+ *
+ * Sixteen lanes per frame, four frames per wave and round.  Lane `sub` of a
+ * group holds the bit pairs k = 16 j + sub, j = 0..6: one load per pair (the
+ * four bytes of two 8-bit samples, 2-byte aligned; eight bytes for sc16), so a
+ * group reads 64 contiguous bytes per load.  A compare's wave mask holds 16
+ * message bits of each of the four frames; the CRC is the XOR over set bits
+ * of x^n mod G, reduced over the 16 lanes of a DPP row.
  */
-/* the entries of c_crc_pow a lane can need, fetched once per wave */
-struct lane_powers {
-    uint32_t long_lo;	/* x^(111 - lane): bit `lane` of an 88-bit span */
-    uint32_t long_hi;	/* x^(47 - lane): bit 64 + lane, lane < 24 */
-    uint32_t short_lo;	/* x^(55 - lane): bit `lane` of a 32-bit span, lane < 32 */
-    uint32_t own_lo;	/* x^lane and x^(64 + lane): the correction lookup */
-    uint32_t own_hi;
+typedef uint32_t u32_a2 __attribute__((aligned(2)));
+
+constexpr int kFramePairs = 7;		/* bit pairs per lane: 7 * 16 = 112 */
+
+/* x^n mod G of the bits a lane holds */
+struct group_powers {
+    uint32_t pl[6];	/* x^(111 - k): bit k of the 88-bit span of a long message */
+    uint32_t ps[2];	/* x^(55 - k): bit k of the 32-bit span of a short one */
 };
 
-__device__ __forceinline__ lane_powers
-load_lane_powers(uint32_t lane) {
-    lane_powers w;
-    w.long_lo = c_crc_pow.r[111 - lane];
-    w.long_hi = c_crc_pow.r[lane < 24? 47 - lane : 0];
-    w.short_lo = c_crc_pow.r[lane < 32? 55 - lane : 0];
-    w.own_lo = c_crc_pow.r[lane];
-    w.own_hi = c_crc_pow.r[lane < 48? 64 + lane : 0];
+__device__ __forceinline__ group_powers
+load_group_powers(uint32_t sub) {
+    group_powers w;
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+	const int k = 16 * j + (int) sub;
+	w.pl[j] = k < 88? c_crc_pow.r[111 - k] : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+	w.ps[j] = c_crc_pow.r[55 - (16 * j + (int) sub)];
     return w;
 }
 
-__device__ __forceinline__ void
-finalize_one(const sora_resolve_args &a, uint64_t f, uint64_t r, const frame_mags &m,
-	uint32_t lane, float *s_amp, const lane_powers &w) {
-    const uint64_t p = sora_rec_pos(r);
+template <bool kWide> struct frame_part {
+    uint32_t w[kWide? 2 * kFramePairs : kFramePairs];
+};
 
-    /* bit k = m[p+17+2k] <= m[p+16+2k], k = lane and k = 64 + lane */
-    unsigned long long lo = __ballot(m.a1 <= m.a0);
-    unsigned long long hi = __ballot(lane < 48 && m.b1 <= m.b0);
+template <bool kWide> __device__ __forceinline__ frame_part<kWide>
+load_frame_part(const uint8_t *iq, uint64_t p, uint32_t sub) {
+    frame_part<kWide> f;
+    if constexpr (kWide) {
+	const uint32_t *src = reinterpret_cast<const uint32_t *>(iq) + (p + 16) + 2 * sub;
+#pragma unroll
+	for (int j = 0; j < kFramePairs; j++) {
+	    f.w[2 * j] = src[32 * j];
+	    f.w[2 * j + 1] = src[32 * j + 1];
+	}
+    } else {
+	const u32_a2 *src = reinterpret_cast<const u32_a2 *>(iq + 2 * (p + 16)) + sub;
+#pragma unroll
+	for (int j = 0; j < kFramePairs; j++)
+	    f.w[j] = src[16 * j];
+    }
+    return f;
+}
+
+/* v of the lane `n` places up in this lane's row of 16, wrapping (row_ror) */
+template <int n> __device__ __forceinline__ uint32_t
+row_rotate(uint32_t v) {
+    return (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x120 + n, 0xf, 0xf, false);
+}
+
+__device__ __forceinline__ uint32_t
+row_xor(uint32_t v) {
+    v ^= row_rotate<8>(v);
+    v ^= row_rotate<4>(v);
+    v ^= row_rotate<2>(v);
+    v ^= row_rotate<1>(v);
+    return v;
+}
+
+__device__ __forceinline__ uint32_t
+row_sum(uint32_t v) {
+    v += row_rotate<8>(v);
+    v += row_rotate<4>(v);
+    v += row_rotate<2>(v);
+    v += row_rotate<1>(v);
+    return v;
+}
+
+__device__ __forceinline__ double
+row_sum(double v) {
+#define SORA_ROW_STEP(n) do { \
+	const uint32_t lo = row_rotate<n>((uint32_t) __double_as_longlong(v)); \
+	const uint32_t hi = row_rotate<n>((uint32_t) (__double_as_longlong(v) >> 32)); \
+	v += __longlong_as_double((long long) (((uint64_t) hi << 32) | lo)); \
+    } while (0)
+    SORA_ROW_STEP(8);
+    SORA_ROW_STEP(4);
+    SORA_ROW_STEP(2);
+    SORA_ROW_STEP(1);
+#undef SORA_ROW_STEP
+    return v;
+}
+
+/*
+ * Four frames, one per row of the wave: frame index f and record r are this
+ * row's.  Every sum below is exact in any order: the 8-bit terms are integers;
+ * the sc16 terms are integer-valued floats below 2^33 (times 2^-31), 56 of
+ * them, so the reference's in-order double accumulation (plane-iq.c:72-73)
+ * never rounds either.
+ */
+template <bool kWide> __device__ __forceinline__ void
+finalize_four(const sora_resolve_args &a, uint64_t f, bool valid, uint64_t r,
+	const frame_part<kWide> &part, uint32_t lane, const group_powers &pw,
+	uint32_t flip, bool any_corrected) {
+    const uint32_t sub = lane & 15, row_shift = lane & 48;
+    uint32_t chunk[kFramePairs];
+    uint32_t x_long = 0, x_short = 0, sum56 = 0;
+    double dsum = 0;
+
+#pragma unroll
+    for (int j = 0; j < kFramePairs; j++) {
+	bool nu;			/* m[p+17+2k] <= m[p+16+2k] */
+	const bool counts = j < 3 || (j == 3 && sub < 8);	/* k < 56 */
+	if constexpr (kWide) {
+	    const uint32_t m0 = sora_mag_sc16(part.w[2 * j]);
+	    const uint32_t m1 = sora_mag_sc16(part.w[2 * j + 1]);
+	    nu = m1 <= m0;		/* non-negative floats order as their bits */
+	    if (j < 4) {
+		const float s = __fadd_rn(__uint_as_float(m0), __uint_as_float(m1));
+		dsum += counts? (double) s : 0.0;
+	    }
+	} else {
+	    const uint32_t x = part.w[j] ^ flip;
+	    const int both = __builtin_amdgcn_sdot4((int) x, (int) x, 0, false);
+	    const int second = __builtin_amdgcn_sdot4((int) x, (int) (x & 0xffff0000u), 0, false);
+	    nu = second <= both - second;
+	    if (j < 4)
+		sum56 += counts? (uint32_t) both : 0u;
+	}
+	const unsigned long long mask = __ballot(nu);
+	chunk[j] = (uint32_t) (mask >> row_shift) & 0xffffu;
+	if (j < 6)
+	    x_long ^= nu? pw.pl[j] : 0u;
+	if (j < 2)
+	    x_short ^= nu? pw.ps[j] : 0u;
+    }
     uint32_t bits[4];
-    bits[0] = __brev((uint32_t) lo);
-    bits[1] = __brev((uint32_t) (lo >> 32));
-    bits[2] = __brev((uint32_t) hi);
-    bits[3] = __brev((uint32_t) (hi >> 32)) & 0xffff0000u;
+    bits[0] = __brev(chunk[0] | (chunk[1] << 16));
+    bits[1] = __brev(chunk[2] | (chunk[3] << 16));
+    bits[2] = __brev(chunk[4] | (chunk[5] << 16));
+    bits[3] = __brev(chunk[6]);
 
     /* plane.c:461-475 */
     const uint32_t df = bits[0] >> 27;
     const bool is_long = df >= 16 && df <= 24;
-    const int covered = is_long? 88 : 32;
-    uint32_t x = 0;
-    if ((int) lane < covered && ((lo >> lane) & 1))
-	x = is_long? w.long_lo : w.short_lo;		/* x^(covered + 23 - lane) */
-    if ((int) lane + 64 < covered && ((hi >> lane) & 1))
-	x ^= w.long_hi;					/* x^(covered + 23 - 64 - lane) */
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1)
-	x ^= __shfl_xor(x, d, 64);
+    const uint32_t crc = row_xor(is_long? x_long : x_short);
     const uint32_t ap = is_long? (((bits[2] & 0xffu) << 16) | (bits[3] >> 16))
 	    : (bits[1] >> 8);
-    const uint32_t syndrome = x ^ ap;
+    const uint32_t syndrome = crc ^ ap;
     const bool squitter = df == 11 || df == 17 || df == 18;
 
     /* option: the scan marked this squitter as one flipped bit away from a
      * clean one; find the bit (syndrome == x^k mod G, b = n - 1 - k) and flip
      * it back */
     int corrected = -1;
-    if ((sora_rec_kind(r) & 3) == SORA_REC_KIND_CORRECTED) {
+    if (any_corrected) {				/* wave-uniform, rare */
+	uint32_t found = 0;
+#pragma unroll
+	for (int j = 0; j < kFramePairs; j++) {
+	    const uint32_t k = 16 * j + sub;
+	    if (c_crc_pow.r[k] == syndrome)
+		found = k + 1;
+	}
+	found = row_sum(found);				/* at most one lane has it */
 	const int nbits = is_long? 112 : 56;
-	const unsigned long long k_lo = __ballot(w.own_lo == syndrome);
-	const unsigned long long k_hi = __ballot(lane < 48 && w.own_hi == syndrome);
-	const int k = k_lo != 0? __builtin_ctzll(k_lo) :
-		k_hi != 0? 64 + __builtin_ctzll(k_hi) : -1;
-	if (k >= 0 && k <= nbits - 6) {
-	    corrected = nbits - 1 - k;
-	    bits[corrected >> 5] ^= 0x80000000u >> (corrected & 31);
+	if ((sora_rec_kind(r) & 3) == SORA_REC_KIND_CORRECTED && found != 0 &&
+		(int) found - 1 <= nbits - 6) {
+	    corrected = nbits - (int) found;
+#pragma unroll
+	    for (int i = 0; i < 4; i++)
+		if ((corrected >> 5) == i)
+		    bits[i] ^= 0x80000000u >> (corrected & 31);
 	}
     }
 
-    /* plane-iq.c:62-73: float (s0+s1)/2 accumulated in double, in order */
-    if (lane < 56)
-	s_amp[lane] = __fmul_rn(__fadd_rn(m.a0, m.a1), 0.5f);
-    uint32_t sum56 = 0;
-    if (a.encoding != SORA_ENC_SC16) {
-	/* integers: M = m * 2^14 exactly */
-	sum56 = lane < 56? (uint32_t) (__fadd_rn(m.a0, m.a1) * 16384.0f) : 0;
-#pragma unroll
-	for (int d = 32; d >= 1; d >>= 1)
-	    sum56 += __shfl_xor(sum56, d, 64);
+    double a56;
+    if constexpr (kWide) {
+	a56 = row_sum(dsum) * (1.0 / 2147483648.0);	/* float (s0+s1)/2, s = m * 2^-30 */
+	sum56 = 0;
+    } else {
+	sum56 = row_sum(sum56);
+	a56 = (double) sum56 * (1.0 / 32768.0);		/* exact: see sora_adsb_frame */
     }
-    __builtin_amdgcn_wave_barrier();
-    if (lane == 0) {
-	double a56;
-	if (a.encoding != SORA_ENC_SC16) {
-	    a56 = (double) sum56 * (1.0 / 32768.0);	/* exact: see sora_adsb_frame */
-	} else {
-	    a56 = 0;
-	    for (int k = 0; k < 56; k++)
-		a56 += (double) s_amp[k];
-	}
+    if (valid && sub == 0) {
 	sora_adsb_frame fr;
-	fr.position = a.base_position + p;
+	fr.position = a.base_position + sora_rec_pos(r);
 	fr.bits[0] = bits[0]; fr.bits[1] = bits[1];
 	fr.bits[2] = bits[2]; fr.bits[3] = bits[3];
 	fr.amplitude_56 = a56;
@@ -924,18 +987,17 @@ finalize_one(const sora_resolve_args &a, uint64_t f, uint64_t r, const frame_mag
 	fr.reserved = 0;
 	a.frames[f] = fr;
     }
-    __builtin_amdgcn_wave_barrier();
 }
 
-constexpr int kFinalizeDepth = 4;	/* frames whose sample fetches are in flight */
+constexpr int kFinalizeDepth = 2;	/* rounds (of four frames) whose sample fetches are in flight */
 
 template <bool kWide>
 __global__ void __launch_bounds__(kSmall)
 finalize_kernel(sora_resolve_args a) {
-    const uint32_t flip16 = a.encoding == SORA_ENC_UC8? 0x8080u : 0u;
-    const lane_powers pw = load_lane_powers(threadIdx.x & 63);
-    __shared__ float s_amp[kSmall / 64][56];
+    const uint32_t flip = a.encoding == SORA_ENC_UC8? 0x80808080u : 0u;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t sub = lane & 15, row = lane >> 4;
+    const group_powers pw = load_group_powers(sub);
     const uint64_t n_waves = (uint64_t) gridDim.x * (kSmall / 64);
     const uint64_t gw = (uint64_t) blockIdx.x * (kSmall / 64) + wave;
     uint64_t total = a.acc_offset[a.regions];
@@ -943,27 +1005,31 @@ finalize_kernel(sora_resolve_args a) {
     if (total > a.frames_cap)
 	total = a.frames_cap;
     /* a wave takes 64 consecutive frames at a time: one coalesced load brings
-     * their records (no dependent record fetch per frame), then the sample
-     * fetches of kFinalizeDepth frames are issued together */
+     * their records (no dependent record fetch per frame); row g of round i
+     * works on frame 4 i + g */
     for (uint64_t batch = gw * 64; batch < total; batch += n_waves * 64) {
 	const uint32_t cnt = total - batch < 64? (uint32_t) (total - batch) : 64u;
 	const uint64_t mine = lane < cnt? a.acc_flat[batch + lane] : 0;
-	const uint32_t mine_lo = (uint32_t) mine, mine_hi = (uint32_t) (mine >> 32);
+	const bool any_corrected =
+		__ballot(lane < cnt && (sora_rec_kind(mine) & 3) == SORA_REC_KIND_CORRECTED) != 0;
 
-	for (uint32_t j = 0; j < cnt; j += kFinalizeDepth) {
+	for (uint32_t j = 0; j < cnt; j += 4 * kFinalizeDepth) {
 	    uint64_t r[kFinalizeDepth];
-	    frame_mags m[kFinalizeDepth];
+	    uint32_t idx[kFinalizeDepth];
+	    frame_part<kWide> part[kFinalizeDepth];
 #pragma unroll
 	    for (int u = 0; u < kFinalizeDepth; u++) {
-		const uint32_t k = j + u < cnt? j + u : cnt - 1;	/* uniform */
-		r[u] = (uint64_t) (uint32_t) __builtin_amdgcn_readlane((int) mine_lo, (int) k) |
-			((uint64_t) (uint32_t) __builtin_amdgcn_readlane((int) mine_hi, (int) k) << 32);
-		m[u] = load_frame_mags<kWide>(a.iq, sora_rec_pos(r[u]), lane, flip16);
+		idx[u] = j + 4 * u + row;
+		const uint32_t k = idx[u] < cnt? idx[u] : cnt - 1;
+		r[u] = (uint64_t) (uint32_t) __shfl((int) (uint32_t) mine, (int) k, 64) |
+			((uint64_t) (uint32_t) __shfl((int) (uint32_t) (mine >> 32), (int) k, 64) << 32);
+		part[u] = load_frame_part<kWide>(a.iq, sora_rec_pos(r[u]), sub);
 	    }
 #pragma unroll
 	    for (int u = 0; u < kFinalizeDepth; u++)
-		if (j + u < cnt)
-		    finalize_one(a, batch + j + u, r[u], m[u], lane, s_amp[wave], pw);
+		if (j + 4 * u < cnt)				/* wave-uniform */
+		    finalize_four<kWide>(a, batch + idx[u], idx[u] < cnt, r[u], part[u],
+			    lane, pw, flip, any_corrected);
 	}
     }
 }
