@@ -648,12 +648,20 @@ export_first_kernel(sora_resolve_args a, uint64_t *dst, uint64_t dst_cap,
 /*
  * The stateful rule of plane.c:479-483 as a pure function: a reply at global
  * position P with address A is accepted iff first_seen[A] < P.  Each wave
- * takes a contiguous quarter of one scan region and compacts it, in order,
- * into an accepted region of its own (region = 4 * group + wave): no
- * barriers, four independent record loads in flight per lane.
+ * takes a contiguous part of one scan region (kFilterParts parts per region)
+ * and compacts it, in order, into an accepted region of its own
+ * (region = kFilterParts * group + part): no barriers, eight independent
+ * record loads in flight per lane.
  */
 constexpr int kFilterWaves = kSmall / 64;
 constexpr int kFilterUnroll = 8;
+#ifndef SORA_FILTER_SPLIT
+#define SORA_FILTER_SPLIT 2
+#endif
+/* workgroups per scan region: a wave's loop is one round trip to HBM per
+ * iteration, so the kernel is as fast as there are waves to overlap them */
+constexpr int kFilterSplit = SORA_FILTER_SPLIT;
+constexpr int kFilterParts = kFilterSplit * kFilterWaves;
 
 __global__ void __launch_bounds__(kSmall)
 filter_kernel(sora_resolve_args a) {
@@ -662,8 +670,9 @@ filter_kernel(sora_resolve_args a) {
      * those go on to the exact bitmap and the first-seen table in L2 */
     __shared__ uint32_t s_fold[SORA_KNOWN_FOLD_WORDS];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t group = blockIdx.x;
-    const uint32_t region = group * kFilterWaves + wave;
+    const uint32_t group = blockIdx.x / kFilterSplit;
+    const uint32_t part = (blockIdx.x % kFilterSplit) * kFilterWaves + wave;
+    const uint32_t region = group * kFilterParts + part;
     const uint64_t *rec = a.rec + (uint64_t) group * a.rec_cap;
     uint64_t *acc = a.acc + (uint64_t) region * a.acc_cap;
     uint32_t n = a.rec_count[group];
@@ -679,8 +688,8 @@ filter_kernel(sora_resolve_args a) {
 
     if (n > a.rec_cap)
 	n = a.rec_cap;
-    const uint32_t begin = (uint32_t) ((uint64_t) n * wave / kFilterWaves);
-    const uint32_t end = (uint32_t) ((uint64_t) n * (wave + 1) / kFilterWaves);
+    const uint32_t begin = (uint32_t) ((uint64_t) n * part / kFilterParts);
+    const uint32_t end = (uint32_t) ((uint64_t) n * (part + 1) / kFilterParts);
 
     for (uint32_t base = begin; base < end; base += 64 * kFilterUnroll) {
 	uint64_t r[kFilterUnroll];
@@ -1141,14 +1150,14 @@ sora_launch_export_first(const sora_resolve_args *a, uint64_t *dst, uint64_t dst
 hipError_t
 sora_launch_filter(const sora_resolve_args *a, hipStream_t stream) {
     (void) hipGetLastError();
-    hipLaunchKernelGGL(filter_kernel, dim3(a->groups), dim3(kSmall), 0, stream,
-	    *a);
+    hipLaunchKernelGGL(filter_kernel, dim3(a->groups * kFilterSplit), dim3(kSmall), 0,
+	    stream, *a);
     return hipGetLastError();
 }
 
 uint32_t
 sora_filter_regions(uint32_t groups) {
-    return groups * kFilterWaves;
+    return groups * kFilterParts;
 }
 
 hipError_t
