@@ -54,6 +54,9 @@ def parse_args():
     ap.add_argument("--gather", choices=("shm", "collective"), default="shm",
                     help="N>1: frame lists to rank 0 through a shared host segment "
                          "(every rank over its own PCIe link) or by an RCCL gather")
+    ap.add_argument("--overlap", action="store_true",
+                    help="experiment: do not order the kernels of different captures "
+                         "by events (a scan may share the GPU with a resolve)")
     ap.add_argument("--force-collective", action="store_true",
                     help="run the N>1 exchange code path even with one rank (rehearsal)")
     return ap.parse_args()
@@ -248,7 +251,7 @@ def main():
             d = decs[i % n_dec]
             if n_dec == 1 and prev is not None:
                 n, prev = finish(prev), None
-            if resolved is not None:
+            if resolved is not None and not args.overlap:
                 streams[i % n_dec].wait_event(resolved)    # S(i) behind R(i-1)
             timed("begin", d.begin, *job)  # reset (a new capture) + scan, asynchronous
             if prev is not None:

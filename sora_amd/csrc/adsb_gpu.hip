@@ -25,7 +25,8 @@ struct sora_adsb_ctx {
 
     sora_adsb_config cfg;
     uint32_t max_groups;	/* workgroups the scan kernel may use */
-    uint32_t max_regions;	/* accepted regions (sora_filter_regions) */
+    uint32_t scan_rounds, scan_min_tiles;	/* see sora_adsb_create() */
+    uint32_t max_regions;	/* accepted regions (sora_filter_max_regions) */
     uint32_t cus;
     uint64_t rec_total, sq_total, acc_total, frames_cap;
 
@@ -95,6 +96,19 @@ void stream_release(sora_adsb_ctx *ctx);
 	if (e_ != hipSuccess) \
 	    return fail((ctx), SORA_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_)); \
     } while (0)
+
+constexpr uint32_t kScanRounds = 16;	/* rounds of scan workgroups per CU */
+constexpr uint32_t kMinTiles = 8;	/* tiles per workgroup, at least */
+
+uint32_t
+env_number(const char *name, uint32_t fallback, long lo, long hi) {
+    const char *e = getenv(name);
+    if (e == nullptr || *e == '\0')
+	return fallback;
+    char *end = nullptr;
+    const long v = strtol(e, &end, 10);
+    return *end == '\0' && v >= lo && v <= hi? (uint32_t) v : fallback;
+}
 
 int
 bytes_per_sample(int encoding) {
@@ -244,8 +258,17 @@ sora_adsb_create(sora_adsb_ctx **out, int device, const sora_adsb_config *cfg) {
     /* the scan kernels run sora_scan_groups_per_cu() workgroups on every CU
      * (what their LDS lets a CU hold): at most 4 */
     ctx->cus = prop.multiProcessorCount > 0? (uint32_t) prop.multiProcessorCount : 1;
-    ctx->max_groups = ctx->cus * 8;
-    ctx->max_regions = sora_filter_regions(ctx->max_groups);
+    /* ... in kScanRounds rounds: a workgroup takes a range of tiles a sixteenth
+     * of what a resident one would, so CUs that run ahead (clock, HBM channel
+     * luck) take more ranges instead of waiting for the slowest: measured 3.67
+     * -> 3.39 ms on the 1-hour capture, flat from 16 to 24 rounds.  A range is at
+     * least kMinTiles tiles (the CRC tables are loaded into LDS once per range).
+     * SORA_ADSB_SCAN_ROUNDS / SORA_ADSB_SCAN_MIN_TILES override both (tuning and
+     * tests). */
+    ctx->scan_rounds = env_number("SORA_ADSB_SCAN_ROUNDS", kScanRounds, 1, 64);
+    ctx->scan_min_tiles = env_number("SORA_ADSB_SCAN_MIN_TILES", kMinTiles, 1, 1 << 20);
+    ctx->max_groups = ctx->cus * 4 * ctx->scan_rounds;
+    ctx->max_regions = sora_filter_max_regions(ctx->max_groups);
 
     const uint64_t n = cfg->max_chunk_samples;
     ctx->rec_total = cfg->max_candidates != 0? cfg->max_candidates : n / 16 + 65536;
@@ -313,9 +336,9 @@ sora_adsb_scan(sora_adsb_ctx *ctx, const void *d_iq, size_t nbytes, int encoding
     if (n_owned < n_scan)
 	n_scan = n_owned;
     const uint64_t n_tiles = sora_scan_tiles(n_scan, encoding);
-    uint32_t groups = ctx->cus * sora_scan_groups_per_cu(encoding);
-    if (n_tiles < groups)
-	groups = n_tiles > 0? (uint32_t) n_tiles : 1;
+    uint32_t groups = ctx->cus * sora_scan_groups_per_cu(encoding) * ctx->scan_rounds;
+    if (n_tiles / ctx->scan_min_tiles < groups)
+	groups = n_tiles >= ctx->scan_min_tiles? (uint32_t) (n_tiles / ctx->scan_min_tiles) : 1;
 
     sora_scan_args &a = ctx->scan;
     memset(&a, 0, sizeof a);
@@ -352,7 +375,8 @@ sora_adsb_scan(sora_adsb_ctx *ctx, const void *d_iq, size_t nbytes, int encoding
     r.sq_cap = a.sq_cap;
     r.first_seen = ctx->d_first_seen;
     r.known_bits = ctx->d_known_bits;
-    r.regions = sora_filter_regions(groups);
+    r.filter_parts = sora_filter_parts(groups);
+    r.regions = groups * r.filter_parts;
     r.acc = ctx->d_acc;
     r.acc_count = ctx->d_acc_count;
     r.acc_cap = (uint32_t) (ctx->acc_total / r.regions > 0x7fffffffull?

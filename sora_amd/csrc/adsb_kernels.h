@@ -62,7 +62,8 @@ struct sora_resolve_args {
     uint32_t *known_bits;	/* [SORA_KNOWN_WORDS] bitmap of the addresses in
 				 * first_seen, then its 2^17-bit fold
 				 * (bit addr & 0x1ffff) for the filter's LDS */
-    uint32_t regions;		/* accepted regions: sora_filter_regions(groups) */
+    uint32_t regions;		/* accepted regions: groups * filter_parts */
+    uint32_t filter_parts;	/* sora_filter_parts(groups) */
     uint64_t *acc;		/* [regions][acc_cap] accepted records */
     uint32_t *acc_count;	/* [regions] */
     uint32_t acc_cap;
@@ -95,7 +96,8 @@ hipError_t sora_launch_filter(const struct sora_resolve_args *a,
 	hipStream_t stream);
 hipError_t sora_launch_scan_counts(const uint32_t *counts, uint32_t cap,
 	uint64_t *offsets, uint32_t n, hipStream_t stream);
-uint32_t sora_filter_regions(uint32_t groups);
+uint32_t sora_filter_parts(uint32_t groups);		/* accepted regions per scan region */
+uint32_t sora_filter_max_regions(uint32_t max_groups);
 /* flattens the accepted regions (needs acc_offset) and re-slices the frames */
 hipError_t sora_launch_finalize(const struct sora_resolve_args *a, uint32_t cus,
 	hipStream_t stream);

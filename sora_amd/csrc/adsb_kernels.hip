@@ -648,20 +648,17 @@ export_first_kernel(sora_resolve_args a, uint64_t *dst, uint64_t dst_cap,
 /*
  * The stateful rule of plane.c:479-483 as a pure function: a reply at global
  * position P with address A is accepted iff first_seen[A] < P.  Each wave
- * takes a contiguous part of one scan region (kFilterParts parts per region)
+ * takes a contiguous part of one scan region (a.filter_parts parts per region)
  * and compacts it, in order, into an accepted region of its own
- * (region = kFilterParts * group + part): no barriers, eight independent
+ * (region = filter_parts * group + part): no barriers, eight independent
  * record loads in flight per lane.
  */
 constexpr int kFilterWaves = kSmall / 64;
 constexpr int kFilterUnroll = 8;
-#ifndef SORA_FILTER_SPLIT
-#define SORA_FILTER_SPLIT 2
-#endif
-/* workgroups per scan region: a wave's loop is one round trip to HBM per
- * iteration, so the kernel is as fast as there are waves to overlap them */
-constexpr int kFilterSplit = SORA_FILTER_SPLIT;
-constexpr int kFilterParts = kFilterSplit * kFilterWaves;
+/* a wave's loop is one round trip to HBM per iteration, so the kernel is as fast
+ * as there are waves to overlap them: regions are split until there are this
+ * many parts (24 waves per CU of a 256-CU part) */
+constexpr uint32_t kFilterTargetParts = 6144;
 
 __global__ void __launch_bounds__(kSmall)
 filter_kernel(sora_resolve_args a) {
@@ -670,14 +667,7 @@ filter_kernel(sora_resolve_args a) {
      * those go on to the exact bitmap and the first-seen table in L2 */
     __shared__ uint32_t s_fold[SORA_KNOWN_FOLD_WORDS];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t group = blockIdx.x / kFilterSplit;
-    const uint32_t part = (blockIdx.x % kFilterSplit) * kFilterWaves + wave;
-    const uint32_t region = group * kFilterParts + part;
-    const uint64_t *rec = a.rec + (uint64_t) group * a.rec_cap;
-    uint64_t *acc = a.acc + (uint64_t) region * a.acc_cap;
-    uint32_t n = a.rec_count[group];
-    uint32_t n_acc = 0;
-
+    const uint32_t region = blockIdx.x * kFilterWaves + wave;
     {
 	const u32x4 *src = reinterpret_cast<const u32x4 *>(a.known_bits +
 		SORA_KNOWN_BITMAP_WORDS);
@@ -685,11 +675,19 @@ filter_kernel(sora_resolve_args a) {
 	    *reinterpret_cast<u32x4 *>(&s_fold[4 * i]) = src[i];
     }
     __syncthreads();
+    if (region >= a.regions)		/* wave-uniform; no barrier below */
+	return;
+    const uint32_t group = region / a.filter_parts;
+    const uint32_t part = region % a.filter_parts;
+    const uint64_t *rec = a.rec + (uint64_t) group * a.rec_cap;
+    uint64_t *acc = a.acc + (uint64_t) region * a.acc_cap;
+    uint32_t n = a.rec_count[group];
+    uint32_t n_acc = 0;
 
     if (n > a.rec_cap)
 	n = a.rec_cap;
-    const uint32_t begin = (uint32_t) ((uint64_t) n * part / kFilterParts);
-    const uint32_t end = (uint32_t) ((uint64_t) n * (part + 1) / kFilterParts);
+    const uint32_t begin = (uint32_t) ((uint64_t) n * part / a.filter_parts);
+    const uint32_t end = (uint32_t) ((uint64_t) n * (part + 1) / a.filter_parts);
 
     for (uint32_t base = begin; base < end; base += 64 * kFilterUnroll) {
 	uint64_t r[kFilterUnroll];
@@ -1150,14 +1148,23 @@ sora_launch_export_first(const sora_resolve_args *a, uint64_t *dst, uint64_t dst
 hipError_t
 sora_launch_filter(const sora_resolve_args *a, hipStream_t stream) {
     (void) hipGetLastError();
-    hipLaunchKernelGGL(filter_kernel, dim3(a->groups * kFilterSplit), dim3(kSmall), 0,
-	    stream, *a);
+    hipLaunchKernelGGL(filter_kernel, dim3((a->regions + kFilterWaves - 1) / kFilterWaves),
+	    dim3(kSmall), 0, stream, *a);
     return hipGetLastError();
 }
 
 uint32_t
-sora_filter_regions(uint32_t groups) {
-    return groups * kFilterParts;
+sora_filter_parts(uint32_t groups) {
+    /* at most 8 parts per region: the accepted list's capacity is shared out
+     * over the regions, and a short capture has few scan regions */
+    const uint32_t parts = groups == 0? 1 : (kFilterTargetParts + groups - 1) / groups;
+    return parts > 8? 8 : parts;
+}
+
+uint32_t
+sora_filter_max_regions(uint32_t max_groups) {
+    /* groups * ceil(target / groups) < target + groups */
+    return kFilterTargetParts + max_groups;
 }
 
 hipError_t

@@ -538,3 +538,27 @@ def test_more_hits_than_the_small_queue():
     raw2 = raw + np.random.default_rng(4).integers(0, 256, 2 * 40000, dtype=np.uint8).tobytes()
     got, _ = gpu_frames(raw2)
     assert_same_frames(got, ob.scan(raw2))
+
+
+@pytest.mark.parametrize("min_tiles,rounds", [(1, 16), (3, 1), (8, 2)])
+def test_workgroup_ranges_do_not_matter(monkeypatch, min_tiles, rounds):
+    """The scan hands tile ranges to workgroups (at least SORA_ADSB_SCAN_MIN_TILES
+    tiles each, SORA_ADSB_SCAN_ROUNDS rounds of workgroups per CU); the record
+    regions of the ranges are concatenated.  One tile per workgroup puts every
+    tile edge on a region edge; the result is the same list."""
+    monkeypatch.setenv("SORA_ADSB_SCAN_MIN_TILES", str(min_tiles))
+    monkeypatch.setenv("SORA_ADSB_SCAN_ROUNDS", str(rounds))
+    p = synth.default_params(2, n_samples=1200000, mean_gap=700, reply_permille=200,
+                             unknown_permille=300, n_icao=7, seed=5)
+    raw = synth.fill_host(p.n_samples, p.encoding, p.seed, synth.make_frames(p)).tobytes()
+    want = ob.scan(raw)
+    got, counts = gpu_frames(raw)
+    assert_same_frames(got, want)
+    assert counts["candidates"] == len(want)
+    acc, _ = gpu_frames(raw, emit=EMIT_ACCEPTED)
+    assert_same_frames(acc, [c for c in want if c["accepted"]])
+    p16 = synth.default_params(4, n_samples=300000, seed=6)
+    p16.encoding = ENC_SC16
+    raw = synth.fill_host(p16.n_samples, ENC_SC16, p16.seed, synth.make_frames(p16)).tobytes()
+    got, _ = gpu_frames(raw, ENC_SC16)
+    assert_same_frames(got, ob.scan(raw, ENC_SC16))
