@@ -131,6 +131,11 @@ def cpu_baseline(d_iq, n_cpu, gpu_accepted_in_window):
 
 def main():
     args = parse_args()
+    # stdout carries the one JSON line and nothing else: libraries that print
+    # to fd 1 (RCCL's version banner does) go to stderr for the run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
 
@@ -337,7 +342,8 @@ def main():
         line["cpu_baseline"] = None
 
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     for d in decs:
         d.close()
     for c in ctxs:

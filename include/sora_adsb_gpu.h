@@ -163,6 +163,24 @@ int sora_adsb_add_known(sora_adsb_ctx *ctx, const void *d_records,
 	size_t n_records);
 
 /*
+ * The same exchange with no host synchronisation, for a collective of fixed
+ * size queued on the context's stream (an all-gather of one block per shard):
+ * export_block writes an exchange block into DEVICE memory of the caller --
+ * word 0 the number of records this scan exports, words 1 .. block_records-1
+ * the records (the first block_records-1 of them if there are more);
+ * add_known_blocks merges n_blocks such blocks, laid end to end, into this
+ * context's table, reading every count on the device and leaving out block
+ * skip_block (this shard's own; -1: none).  Both are asynchronous.  A count
+ * above block_records-1 means records were dropped: the caller reads the
+ * counts back when it collects the frames and must then treat the result as
+ * overflowed.  (No counterpart in the reference: plane.c:479-483 is one
+ * sequential validator.)
+ */
+int sora_adsb_export_block(sora_adsb_ctx *ctx, void *d_block, size_t block_records);
+int sora_adsb_add_known_blocks(sora_adsb_ctx *ctx, const void *d_blocks,
+	size_t n_blocks, size_t block_records, int skip_block);
+
+/*
  * Stage 2 -- merges this scan's squitters into the first-seen table, filters
  * the replies against it, sorts the accepted positions and re-slices them
  * into frames (bits, amplitude, syndrome).  Asynchronous.

@@ -117,6 +117,15 @@ class AdsbContext:
     def add_known(self, d_records, n_records):
         check(lib().sora_adsb_add_known(self._h, _ptr(d_records), n_records), self._h)
 
+    def export_block(self, d_block, block_records):
+        """Exchange block (count, then records) into device memory; no host sync."""
+        check(lib().sora_adsb_export_block(self._h, _ptr(d_block), block_records), self._h)
+
+    def add_known_blocks(self, d_blocks, n_blocks, block_records, skip_block=-1):
+        """Merges gathered exchange blocks; counts are read on the device."""
+        check(lib().sora_adsb_add_known_blocks(self._h, _ptr(d_blocks), n_blocks,
+                                               block_records, skip_block), self._h)
+
     def resolve(self):
         check(lib().sora_adsb_resolve(self._h), self._h)
 

@@ -466,6 +466,38 @@ sora_adsb_add_known(sora_adsb_ctx *ctx, const void *d_records, size_t n_records)
 }
 
 extern "C" int
+sora_adsb_export_block(sora_adsb_ctx *ctx, void *d_block, size_t block_records) {
+    if (ctx == nullptr || d_block == nullptr || block_records < 2 ||
+	    block_records > 0xffffffffull)
+	return SORA_ERR_INVALID;
+    if (!ctx->scanned)
+	return fail(ctx, SORA_ERR_STATE, "no scan to export squitters of");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!ctx->merged) {
+	HIP_TRY(ctx, sora_launch_first_seen(&ctx->res, ctx->stream));
+	ctx->merged = true;
+    }
+    uint64_t *blk = static_cast<uint64_t *>(d_block);
+    HIP_TRY(ctx, sora_launch_export_first(&ctx->res, blk + 1, block_records - 1, blk,
+	    ctx->stream));
+    return SORA_OK;
+}
+
+extern "C" int
+sora_adsb_add_known_blocks(sora_adsb_ctx *ctx, const void *d_blocks, size_t n_blocks,
+	size_t block_records, int skip_block) {
+    if (ctx == nullptr || (d_blocks == nullptr && n_blocks != 0) || block_records < 2 ||
+	    block_records > 0xffffffffull || n_blocks > 65535)
+	return SORA_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, sora_launch_add_known_blocks(ctx->d_first_seen, ctx->d_known_bits,
+	    static_cast<const uint64_t *>(d_blocks), (uint32_t) n_blocks,
+	    (uint32_t) block_records, skip_block < 0? 0xffffffffu : (uint32_t) skip_block,
+	    ctx->stream));
+    return SORA_OK;
+}
+
+extern "C" int
 sora_adsb_resolve(sora_adsb_ctx *ctx) {
     if (ctx == nullptr)
 	return SORA_ERR_INVALID;

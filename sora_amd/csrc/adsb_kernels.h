@@ -88,6 +88,11 @@ hipError_t sora_launch_first_seen(const struct sora_resolve_args *a,
 /* same from flat global records (position << 24 | address) */
 hipError_t sora_launch_add_known(uint64_t *first_seen, uint32_t *known_bits,
 	const uint64_t *records, uint64_t n, hipStream_t stream);
+/* same from n_blocks exchange blocks of `stride` words (word 0: record count,
+ * read on the device), leaving out block `skip` */
+hipError_t sora_launch_add_known_blocks(uint64_t *first_seen, uint32_t *known_bits,
+	const uint64_t *blocks, uint32_t n_blocks, uint32_t stride, uint32_t skip,
+	hipStream_t stream);
 /* per address the earliest squitter of this scan (needs first_seen) -> flat
  * global records, unordered; *counter = how many there are (may exceed cap) */
 hipError_t sora_launch_export_first(const struct sora_resolve_args *a, uint64_t *dst,

@@ -574,6 +574,29 @@ add_known_kernel(uint64_t *first_seen, uint32_t *known_bits,
     }
 }
 
+/*
+ * The exchange blocks of several shards, as an all-gather leaves them: block b
+ * is `stride` words, word 0 the number of records the shard exported, then the
+ * records.  The count is read here, on the device: no host round trip between
+ * the collective and the resolve.  Block `skip` (this shard's own) is left out.
+ */
+__global__ void
+add_known_blocks_kernel(uint64_t *first_seen, uint32_t *known_bits,
+	const uint64_t *blocks, uint32_t stride, uint32_t skip) {
+    const uint32_t b = blockIdx.y;
+    if (b == skip)
+	return;
+    const uint64_t *blk = blocks + (uint64_t) b * stride;
+    uint64_t n = blk[0];
+    if (n > stride - 1)
+	n = stride - 1;			/* the host reports the overflow */
+    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n;
+	    i += (uint64_t) gridDim.x * blockDim.x) {
+	const uint64_t r = blk[1 + i];
+	note_known(first_seen, known_bits, (uint32_t) r & 0xffffffu, r >> 24);
+    }
+}
+
 /* offsets[i] = sum_{j<i} min(counts[j], cap); offsets[n] = total.  One block. */
 __global__ void __launch_bounds__(1024)
 scan_counts_kernel(const uint32_t *counts, uint32_t cap, uint64_t *offsets,
@@ -1121,6 +1144,19 @@ sora_launch_add_known(uint64_t *first_seen, uint32_t *known_bits,
     (void) hipGetLastError();
     hipLaunchKernelGGL(add_known_kernel, dim3(grid_for(n, 256)), dim3(256), 0,
 	    stream, first_seen, known_bits, records, n);
+    return hipGetLastError();
+}
+
+hipError_t
+sora_launch_add_known_blocks(uint64_t *first_seen, uint32_t *known_bits,
+	const uint64_t *blocks, uint32_t n_blocks, uint32_t stride, uint32_t skip,
+	hipStream_t stream) {
+    if (n_blocks == 0 || stride < 2)
+	return hipSuccess;
+    (void) hipGetLastError();
+    hipLaunchKernelGGL(add_known_blocks_kernel, dim3(grid_for(stride - 1, 256) > 16?
+	    16 : grid_for(stride - 1, 256), n_blocks), dim3(256), 0, stream,
+	    first_seen, known_bits, blocks, stride, skip);
     return hipGetLastError();
 }
 

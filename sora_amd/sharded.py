@@ -7,7 +7,10 @@ earliest clean squitter (position << 24 | address, 8 bytes; a few hundred
 records per hour) is all-gathered so that each rank's first-seen table knows
 the addresses earlier ranks introduced
 (`torch.distributed`: backend nccl = RCCL over xGMI on the GPUs, gloo in the
-CPU tests).  Sample data never moves.
+CPU tests).  It is ONE all-gather of a fixed-size block per rank (count, then
+records), queued on the context's stream between the scan and the resolve:
+the counts are read on the device, so the host never waits inside a step.
+Sample data never moves.
 
 The frame lists go to the host, not to another GPU: the ranks of one node
 share a host-memory segment (/dev/shm) with one slot per rank, and every rank
@@ -22,9 +25,9 @@ it crossing xGMI or queueing on one PCIe link.  `gather="collective"` keeps
 the plain RCCL gather to rank 0 (ranks on several nodes).
 
 A step is three phases so that two decoders (two contexts, two streams) can be
-interleaved: begin() launches the scan, exchange() waits for its squitter
-count, exchanges the records and launches the resolve, finish() waits for the
-frames and places them.  step() runs the three in a row.
+interleaved: begin() launches the scan, exchange() queues the export, the
+all-gather and the resolve behind it, finish() waits for the frames and places
+them.  step() runs the three in a row.
 """
 import contextlib
 import os
@@ -38,6 +41,7 @@ from ._lib import BYTES_PER_SAMPLE, FRAME_DTYPE, HALO
 
 FRAME_BYTES = FRAME_DTYPE.itemsize
 HEADER_WORDS = 8                    # u64 per rank: seq, n_frames, ack (rank 0), pad
+EXCHANGE_RECORDS = 8192             # words of a rank's exchange block: count + records
 SPIN_TIMEOUT_S = 300.0
 
 
@@ -99,16 +103,17 @@ class ShardedDecoder:
     a CPU stand-in."""
 
     def __init__(self, ctx, rank, world, device, max_frames, group=None, stream=None,
-                 gather="shm"):
+                 gather="shm", exchange_records=EXCHANGE_RECORDS):
         self.ctx, self.rank, self.world = ctx, rank, world
         self.device, self.max_frames, self.group = device, int(max_frames), group
         self.stream, self.gather = stream, gather
         self.cuda = device.type == "cuda"
-        # exchange records: one per address a shard saw first, not one per squitter
-        self.max_records = min(self.max_frames, 1 << 20)
-        self.d_sq = torch.zeros(self.max_records, dtype=torch.int64, device=device)
-        self.d_sq_all = torch.zeros(world * self.max_records, dtype=torch.int64,
-                                    device=device)
+        # exchange block: word 0 the count, then one record per address this shard
+        # saw first (not one per squitter)
+        self.block = max(2, int(exchange_records))
+        self.d_blk = torch.zeros(self.block, dtype=torch.int64, device=device)
+        self.d_blk_all = torch.zeros(world * self.block, dtype=torch.int64, device=device)
+        self.h_exported = torch.zeros(world, dtype=torch.int64, pin_memory=self.cuda)
         self.counts = torch.zeros(world, dtype=torch.int64, device=device)
         self.d_out = torch.zeros(self.max_frames * FRAME_BYTES, dtype=torch.uint8,
                                  device=device)
@@ -208,23 +213,23 @@ class ShardedDecoder:
                       n_owned=n_owned)
 
     def exchange(self):
-        ctx, world, rank = self.ctx, self.world, self.rank
+        ctx, world = self.ctx, self.world
         with self._on_stream():
-            ks = self._all_counts(ctx.squitter_count())
-            if max(ks) > self.max_records:
-                raise RuntimeError(f"{max(ks)} exchange records exceed {self.max_records}")
-            m = max(ks)
-            if m:
-                ctx.copy_squitters(self.d_sq, self.max_records)
-                ctx.synchronize()
-                dist.all_gather_into_tensor(self.d_sq_all[:world * m], self.d_sq[:m],
-                                            group=self.group)
-                if self.cuda and self.stream is None:
-                    torch.cuda.current_stream().synchronize()
-                for r in range(world):
-                    if r != rank and ks[r]:
-                        ctx.add_known(self.d_sq_all[r * m:r * m + ks[r]], ks[r])
+            ctx.export_block(self.d_blk, self.block)
+            dist.all_gather_into_tensor(self.d_blk_all, self.d_blk, group=self.group)
+            ctx.add_known_blocks(self.d_blk_all, world, self.block, skip_block=self.rank)
             ctx.resolve()
+            # what every rank exported, for the overflow check in finish()
+            self.h_exported.copy_(self.d_blk_all.view(world, self.block)[:, 0],
+                                  non_blocking=True)
+
+    def _check_exported(self):
+        """Behind the wait for the frames: a rank that saw more new addresses than
+        its block holds dropped some, and every rank's result is then wrong."""
+        most = int(self.h_exported.max())
+        if most > self.block - 1:
+            raise RuntimeError(f"{most} exchange records exceed the block of "
+                               f"{self.block - 1}: raise exchange_records")
 
     def finish(self):
         """Total number of frames (all ranks); on rank 0, frames() returns them in
@@ -263,6 +268,7 @@ class ShardedDecoder:
                 if self.cuda:
                     events[i].synchronize()
                 self.h_slot_t[a:b].copy_(self.h_stage_t[a:b])
+        self._check_exported()
         # publish: count first, then the sequence number the others wait for
         self.header[r, 1] = n
         self.header[r, 0] = self.seq
@@ -273,6 +279,7 @@ class ShardedDecoder:
     def _finish_collective(self):
         ctx, world, rank = self.ctx, self.world, self.rank
         ns = self._all_counts(ctx.collect_device(self.d_out, self.max_frames))
+        self._check_exported()
         if max(ns) > self.max_frames:
             raise RuntimeError(f"{max(ns)} frames exceed max_frames")
         self.ns = ns

@@ -168,6 +168,43 @@ def test_shard_exchange_equals_whole():
     assert_same_frames(got, want)
 
 
+@pytest.mark.parametrize("block", [64, 3])
+def test_shard_exchange_blocks_equal_whole(block):
+    """The same exchange with no host synchronisation: export_block writes
+    (count, records) on the device, the blocks of all shards lie end to end as an
+    all-gather leaves them, add_known_blocks reads the counts on the device.  A
+    block too small for a shard's addresses shows in its count."""
+    import torch
+    p = synth.default_params(2, n_samples=800000, mean_gap=1000, reply_permille=300,
+                             unknown_permille=200, n_icao=4, seed=5)
+    raw = synth.fill_host(p.n_samples, p.encoding, p.seed, synth.make_frames(p)).tobytes()
+    want = [c for c in ob.scan(raw) if c["accepted"]]
+    half = 400000
+    shards = [(0, half, half + 239), (half, p.n_samples - half, p.n_samples - half)]
+    ctxs = [AdsbContext(half + 239) for _ in shards]
+    blocks = torch.full((2 * block,), -1, dtype=torch.int64, device="cuda")
+    bufs = []
+    for i, (ctx, (a, owned, n)) in enumerate(zip(ctxs, shards)):
+        bufs.append(DeviceBuffer.from_host(raw[2 * a:2 * (a + n)] + bytes(16)))
+        ctx.scan(bufs[-1], 2 * n, ENC_UC8, base_position=a, n_owned=owned)
+        ctx.export_block(blocks[i * block:], block)
+        ctx.synchronize()
+    counts = blocks.view(2, block)[:, 0].tolist()
+    assert counts == [ctx.squitter_count() for ctx in ctxs] and all(1 <= k <= 4 for k in counts)
+    if block == 3:
+        assert max(counts) > block - 1          # what ShardedDecoder.finish() raises on
+        for ctx in ctxs:
+            ctx.close()
+        return
+    got = []
+    for i, ctx in enumerate(ctxs):
+        ctx.add_known_blocks(blocks, 2, block, skip_block=i)
+        ctx.resolve()
+        got += frames_as_dicts(ctx.collect())
+        ctx.close()
+    assert_same_frames(got, want)
+
+
 def test_overflow_is_reported():
     rng = np.random.default_rng(1)
     raw = rng.integers(0, 256, size=2 * 200000, dtype=np.uint8).tobytes()

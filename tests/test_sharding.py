@@ -44,6 +44,23 @@ class OracleContext:
         rec = [(c["position"] << 24) | c["address"] for c in self.squitters][:cap]
         d_dst[:len(rec)] = torch.tensor(rec, dtype=torch.int64)
 
+    def export_block(self, d_block, block_records):
+        first = {}
+        for c in self.squitters:
+            first[c["address"]] = min(first.get(c["address"], 1 << 62), c["position"])
+        rec = [(pos << 24) | a for a, pos in sorted(first.items())]
+        d_block[0] = len(rec)
+        rec = rec[:block_records - 1]
+        d_block[1:1 + len(rec)] = torch.tensor(rec, dtype=torch.int64)
+
+    def add_known_blocks(self, d_blocks, n_blocks, block_records, skip_block=-1):
+        for b in range(n_blocks):
+            if b == skip_block:
+                continue
+            blk = d_blocks[b * block_records:(b + 1) * block_records]
+            n = min(int(blk[0]), block_records - 1)
+            self.add_known(blk[1:], n)
+
     def synchronize(self):
         pass
 
@@ -84,7 +101,7 @@ class OracleContext:
         return len(self.frames)
 
 
-def _worker(rank, world, port, raw, result_path, gather):
+def _worker(rank, world, port, raw, result_path, gather, exchange_records=64):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -95,7 +112,8 @@ def _worker(rank, world, port, raw, result_path, gather):
                                  dtype=torch.uint8)
         # two decoders interleaved the way bench.py pipelines them
         decs = [ShardedDecoder(OracleContext(), rank, world, torch.device("cpu"), 20000,
-                               gather=gather) for _ in range(2)]
+                               gather=gather, exchange_records=exchange_records)
+                for _ in range(2)]
         args = (shard, 2 * local, ob.ENC_UC8, first, owned)
         decs[0].begin(*args)
         decs[0].exchange()
@@ -165,3 +183,26 @@ def test_local_decoder_phases():
     want = [c for c in ob.scan(raw) if c["accepted"]]
     assert n == len(want) > 10
     assert [int(f["position"]) for f in dec.frames()] == [c["position"] for c in want]
+
+
+def _overflow_worker(rank, world, port, raw, path):
+    try:
+        _worker(rank, world, port, raw, path, "shm", exchange_records=3)
+    except RuntimeError as e:
+        assert "exchange records exceed" in str(e)
+        with open(f"{path}.{rank}.raised", "w") as fh:
+            fh.write(str(e))
+
+
+@pytest.mark.timeout(300)
+def test_exchange_block_overflow_is_reported(tmp_path):
+    """A block too small for the addresses a shard saw first must not pass
+    silently: every rank raises when it collects its frames."""
+    p = synth.default_params(2, n_samples=200000, mean_gap=900, n_icao=5, seed=21)
+    raw = synth.fill_host(p.n_samples, p.encoding, p.seed, synth.make_frames(p)).tobytes()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "frames.npy")
+    mp.spawn(_overflow_worker, args=(2, port, raw, out), nprocs=2, join=True)
+    assert os.path.exists(out + ".0.raised") and os.path.exists(out + ".1.raised")
