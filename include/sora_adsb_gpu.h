@@ -252,6 +252,15 @@ int sora_adsb_copy_to_device(int device, void *d_dst, const void *h_src,
 int sora_adsb_copy_to_host(int device, void *h_dst, const void *d_src,
 	size_t nbytes);
 /*
+ * Host memory to host memory with non-temporal stores: for moving a frame
+ * list from a pinned staging buffer into memory shared between the ranks of a
+ * node (where the segment cannot be page-locked, see below) without reading
+ * the destination first.  Touches no device.  (No counterpart in the
+ * reference.)
+ */
+int sora_adsb_host_copy(void *dst, const void *src, size_t nbytes);
+
+/*
  * Page-locks host memory the caller owns (for example a shared-memory segment
  * that several per-GPU processes write their frame lists into) so that
  * sora_adsb_collect() copies into it by DMA at full PCIe rate.  No counterpart

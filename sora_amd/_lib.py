@@ -127,6 +127,7 @@ _SIGNATURES = {
     "sora_adsb_squitter_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "sora_adsb_copy_squitters": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "sora_adsb_add_known": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "sora_adsb_host_copy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "sora_adsb_export_block": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "sora_adsb_add_known_blocks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t,
                                              C.c_int]),

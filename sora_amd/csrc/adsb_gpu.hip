@@ -917,6 +917,43 @@ sora_adsb_copy_to_host(int device, void *h_dst, const void *d_src, size_t nbytes
 	    SORA_OK : SORA_ERR_HIP;
 }
 
+/*
+ * Host-to-host copy that does not read the destination's cache lines first:
+ * 16-byte non-temporal stores (movntdq), for moving a frame list from a pinned
+ * staging buffer into memory shared between processes.  With several ranks of
+ * a node copying at once the memory bus is what is shared, and a plain memcpy
+ * below glibc's non-temporal threshold moves every line three times (read
+ * source, read destination for ownership, write back) instead of twice.
+ */
+extern "C" int
+sora_adsb_host_copy(void *dst, const void *src, size_t nbytes) {
+    if ((dst == nullptr || src == nullptr) && nbytes != 0)
+	return SORA_ERR_INVALID;
+    typedef long long v2di __attribute__((vector_size(16)));
+    typedef long long v2di_u __attribute__((vector_size(16), aligned(1)));
+    unsigned char *d = static_cast<unsigned char *>(dst);
+    const unsigned char *s = static_cast<const unsigned char *>(src);
+    size_t head = (16 - (reinterpret_cast<uintptr_t>(d) & 15)) & 15;
+    if (head > nbytes)
+	head = nbytes;
+    memcpy(d, s, head);
+    d += head; s += head; nbytes -= head;
+    size_t body = nbytes & ~(size_t) 63;
+    for (size_t i = 0; i < body; i += 64) {
+	const v2di a0 = *reinterpret_cast<const v2di_u *>(s + i);
+	const v2di a1 = *reinterpret_cast<const v2di_u *>(s + i + 16);
+	const v2di a2 = *reinterpret_cast<const v2di_u *>(s + i + 32);
+	const v2di a3 = *reinterpret_cast<const v2di_u *>(s + i + 48);
+	__builtin_nontemporal_store(a0, reinterpret_cast<v2di *>(d + i));
+	__builtin_nontemporal_store(a1, reinterpret_cast<v2di *>(d + i + 16));
+	__builtin_nontemporal_store(a2, reinterpret_cast<v2di *>(d + i + 32));
+	__builtin_nontemporal_store(a3, reinterpret_cast<v2di *>(d + i + 48));
+    }
+    memcpy(d + body, s + body, nbytes - body);
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);	/* mfence: orders the streaming stores */
+    return SORA_OK;
+}
+
 extern "C" int
 sora_adsb_host_register(int device, void *h_ptr, size_t nbytes) {
     if (h_ptr == nullptr || nbytes == 0)

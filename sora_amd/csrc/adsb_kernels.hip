@@ -597,47 +597,40 @@ add_known_blocks_kernel(uint64_t *first_seen, uint32_t *known_bits,
     }
 }
 
-/* offsets[i] = sum_{j<i} min(counts[j], cap); offsets[n] = total.  One block. */
+/* offsets[i] = sum_{j<i} min(counts[j], cap); offsets[n] = total.  One block:
+ * every thread sums a run of consecutive counts, the block scans the 1024
+ * sums, every thread writes its run's offsets. */
 __global__ void __launch_bounds__(1024)
 scan_counts_kernel(const uint32_t *counts, uint32_t cap, uint64_t *offsets,
 	uint32_t n) {
     __shared__ uint64_t s_wave[16];
-    __shared__ uint64_t s_carry;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t per = (n + 1023) / 1024;
+    const uint32_t begin = tid * per < n? tid * per : n;
+    const uint32_t end = begin + per < n? begin + per : n;
 
-    if (tid == 0)
-	s_carry = 0;
-    __syncthreads();
-    for (uint32_t base = 0; base < n; base += 1024) {
-	uint32_t i = base + tid;
-	uint64_t c = 0;
-	if (i < n) {
-	    c = counts[i];
-	    if (c > cap)
-		c = cap;
-	}
-	uint64_t incl = c;
+    uint64_t sum = 0;
+    for (uint32_t i = begin; i < end; i++)
+	sum += counts[i] < cap? counts[i] : cap;
+    uint64_t incl = sum;
 #pragma unroll
-	for (int d = 1; d < 64; d <<= 1) {
-	    uint64_t o = __shfl_up(incl, d, 64);
-	    if (lane >= (uint32_t) d)
-		incl += o;
-	}
-	if (lane == 63)
-	    s_wave[wave] = incl;
-	__syncthreads();
-	uint64_t pre = s_carry;
-	for (uint32_t w = 0; w < wave; w++)
-	    pre += s_wave[w];
-	if (i < n)
-	    offsets[i] = pre + incl - c;
-	__syncthreads();
-	if (tid == 1023)
-	    s_carry = pre + incl;
-	__syncthreads();
+    for (int d = 1; d < 64; d <<= 1) {
+	uint64_t o = __shfl_up(incl, d, 64);
+	if (lane >= (uint32_t) d)
+	    incl += o;
     }
-    if (tid == 0)
-	offsets[n] = s_carry;
+    if (lane == 63)
+	s_wave[wave] = incl;
+    __syncthreads();
+    uint64_t pre = incl - sum;
+    for (uint32_t w = 0; w < wave; w++)
+	pre += s_wave[w];
+    for (uint32_t i = begin; i < end; i++) {
+	offsets[i] = pre;
+	pre += counts[i] < cap? counts[i] : cap;
+    }
+    if (tid == 1023)
+	offsets[n] = pre;
 }
 
 /*

@@ -37,6 +37,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+from . import _lib
 from ._lib import BYTES_PER_SAMPLE, FRAME_DTYPE, HALO
 
 FRAME_BYTES = FRAME_DTYPE.itemsize
@@ -162,7 +163,6 @@ class ShardedDecoder:
                                self.max_frames * FRAME_BYTES].view(FRAME_DTYPE)
                       for r in range(self.world)]
         if self.cuda:
-            from . import _lib
             idx = self.device.index if self.device.index is not None else 0
             rc = _lib.lib().sora_adsb_host_register(idx, self._mm.ctypes.data, nbytes)
             if rc == _lib.OK:
@@ -178,7 +178,6 @@ class ShardedDecoder:
 
     def close(self):
         if self._registered is not None:
-            from . import _lib
             _lib.lib().sora_adsb_host_unregister(*self._registered)
             self._registered = None
         self.header = self.slots = self.h_slot_t = None
@@ -267,7 +266,11 @@ class ShardedDecoder:
             for i, (a, b) in enumerate(zip(cuts, cuts[1:])):
                 if self.cuda:
                     events[i].synchronize()
-                self.h_slot_t[a:b].copy_(self.h_stage_t[a:b])
+                    # non-temporal stores: the ranks of a node copy at the same time
+                    _lib.check(_lib.lib().sora_adsb_host_copy(
+                        self.h_slot_t.data_ptr() + a, self.h_stage_t.data_ptr() + a, b - a))
+                else:
+                    self.h_slot_t[a:b].copy_(self.h_stage_t[a:b])
         self._check_exported()
         # publish: count first, then the sequence number the others wait for
         self.header[r, 1] = n
