@@ -1,4 +1,5 @@
 // Diagnostic: which host memory can hipHostRegister page-lock on this box?
+// build: hipcc -O2 -o tools/probe/host_register_probe tools/probe/host_register_probe.cpp
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
