@@ -404,11 +404,12 @@ adsb_scan_kernel(sora_scan_args a) {
 	{
 	    uint32_t both = pe | po;
 	    while (both != 0) {
-		uint32_t b = __clz(both);
-		uint32_t bit = 0x80000000u >> b;
-		s_queue[off++] = (uint16_t) (tid * SORA_LANE_POS + 2 * b +
-			((po & bit) != 0));
-		both &= ~bit;
+		/* element b of the lane: position 2b (even array) or 2b + 1 (odd
+		 * array; never both, the predicates exclude each other) */
+		const uint32_t b = __clz(both);
+		const uint32_t twice = __builtin_amdgcn_alignbit(b, po << b, 31);
+		s_queue[off++] = (uint16_t) (tid * SORA_LANE_POS | twice);
+		both &= ~(0x80000000u >> b);
 	    }
 	}
 	lds_barrier();
