@@ -290,13 +290,14 @@ def main():
         dt = float(t.item())
 
     counts = ctx.counts()
+    kernel_name = ctx.scan_kernel_name(enc)      # the kernel this context launched
     kernel_ms = float(np.mean(scan_ms))
     # HBM bytes per launch from the PMC passes of this same workload
     # (tools/hbm_traffic.py: FETCH_SIZE x2 + WRITE_SIZE); null if none matches
     traffic = None
     try:
         with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as fh:
-            entry = json.load(fh).get(f"adsb_scan_kernel:{args.encoding}:{n_local * bps}")
+            entry = json.load(fh).get(f"{kernel_name}:{args.encoding}:{n_local * bps}")
         if entry:
             traffic = round(entry["traffic_bytes"])
     except (OSError, ValueError):
@@ -326,8 +327,7 @@ def main():
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-            "kernel": "adsb_scan_kernel<true> (sc16)" if args.encoding == "sc16"
-                      else "adsb_scan_kernel<false> (uc8/sc8)",
+            "kernel": f"{kernel_name} ({args.encoding})",
             "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes": n_local * bps,
         },
     }

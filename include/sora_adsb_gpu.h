@@ -236,6 +236,10 @@ int sora_adsb_synchronize(sora_adsb_ctx *ctx);
 /* Duration of the last scan kernel alone, HIP events on the context's
  * stream, in milliseconds (syncs). */
 int sora_adsb_last_scan_ms(sora_adsb_ctx *ctx, float *ms);
+/* Name of the scan kernel this context launches for `encoding`, as profilers
+ * print it (8-bit encodings: see SORA_ADSB_SCAN_VARIANT in INTEGRATION.md);
+ * "" for a bad argument.  For benchmarks that report per-kernel figures. */
+const char *sora_adsb_scan_kernel_name(const sora_adsb_ctx *ctx, int encoding);
 
 /*
  * Magnitudes only (row a1), for the 1-ulp check north_star asks for:

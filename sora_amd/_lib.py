@@ -148,6 +148,7 @@ _SIGNATURES = {
     "sora_adsb_get_counts": (C.c_int, [C.c_void_p, C.POINTER(Counts)]),
     "sora_adsb_synchronize": (C.c_int, [C.c_void_p]),
     "sora_adsb_last_scan_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "sora_adsb_scan_kernel_name": (C.c_char_p, [C.c_void_p, C.c_int]),
     "sora_adsb_magnitude": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int,
                                       C.c_void_p]),
     "sora_adsb_device_alloc": (C.c_int, [C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]),

@@ -229,6 +229,9 @@ class AdsbContext:
         check(lib().sora_adsb_last_scan_ms(self._h, C.byref(ms)), self._h)
         return ms.value
 
+    def scan_kernel_name(self, encoding):
+        return lib().sora_adsb_scan_kernel_name(self._h, encoding).decode()
+
     def magnitude(self, d_iq, nbytes, encoding, d_m):
         check(lib().sora_adsb_magnitude(self._h, _ptr(d_iq), nbytes, encoding, _ptr(d_m)),
               self._h)

@@ -25,6 +25,7 @@ struct sora_adsb_ctx {
 
     sora_adsb_config cfg;
     uint32_t max_groups;	/* workgroups the scan kernel may use */
+    uint32_t scan_variant;	/* 8-bit scan kernel: 0 M through LDS, 1/2 M in registers (256/512 threads) */
     uint32_t scan_rounds, scan_min_tiles;	/* see sora_adsb_create() */
     uint32_t max_regions;	/* accepted regions (sora_filter_max_regions) */
     uint32_t cus;
@@ -265,9 +266,10 @@ sora_adsb_create(sora_adsb_ctx **out, int device, const sora_adsb_config *cfg) {
      * least kMinTiles tiles (the CRC tables are loaded into LDS once per range).
      * SORA_ADSB_SCAN_ROUNDS / SORA_ADSB_SCAN_MIN_TILES override both (tuning and
      * tests). */
+    ctx->scan_variant = env_number("SORA_ADSB_SCAN_VARIANT", 1, 0, 2);
     ctx->scan_rounds = env_number("SORA_ADSB_SCAN_ROUNDS", kScanRounds, 1, 64);
     ctx->scan_min_tiles = env_number("SORA_ADSB_SCAN_MIN_TILES", kMinTiles, 1, 1 << 20);
-    ctx->max_groups = ctx->cus * 4 * ctx->scan_rounds;
+    ctx->max_groups = ctx->cus * 8 * ctx->scan_rounds;
     ctx->max_regions = sora_filter_max_regions(ctx->max_groups);
 
     const uint64_t n = cfg->max_chunk_samples;
@@ -335,8 +337,8 @@ sora_adsb_scan(sora_adsb_ctx *ctx, const void *d_iq, size_t nbytes, int encoding
     uint64_t n_scan = n_samples >= SORA_ADSB_WINDOW? n_samples - SORA_ADSB_HALO : 0;
     if (n_owned < n_scan)
 	n_scan = n_owned;
-    const uint64_t n_tiles = sora_scan_tiles(n_scan, encoding);
-    uint32_t groups = ctx->cus * sora_scan_groups_per_cu(encoding) * ctx->scan_rounds;
+    const uint64_t n_tiles = sora_scan_tiles(n_scan, encoding, (int) ctx->scan_variant);
+    uint32_t groups = ctx->cus * sora_scan_groups_per_cu(encoding, (int) ctx->scan_variant) * ctx->scan_rounds;
     if (n_tiles / ctx->scan_min_tiles < groups)
 	groups = n_tiles >= ctx->scan_min_tiles? (uint32_t) (n_tiles / ctx->scan_min_tiles) : 1;
 
@@ -392,7 +394,7 @@ sora_adsb_scan(sora_adsb_ctx *ctx, const void *d_iq, size_t nbytes, int encoding
     ctx->merged = ctx->exported = false;
 
     HIP_TRY(ctx, hipEventRecord(ctx->ev_scan_begin, ctx->stream));
-    HIP_TRY(ctx, sora_launch_scan(&a, groups, ctx->stream));
+    HIP_TRY(ctx, sora_launch_scan(&a, groups, (int) ctx->scan_variant, ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_scan_end, ctx->stream));
     ctx->scan_timed = true;
     ctx->scanned = true;
@@ -860,6 +862,16 @@ sora_adsb_last_scan_ms(sora_adsb_ctx *ctx, float *ms) {
     HIP_TRY(ctx, hipEventSynchronize(ctx->ev_scan_end));
     HIP_TRY(ctx, hipEventElapsedTime(ms, ctx->ev_scan_begin, ctx->ev_scan_end));
     return SORA_OK;
+}
+
+extern "C" const char *
+sora_adsb_scan_kernel_name(const sora_adsb_ctx *ctx, int encoding) {
+    if (ctx == nullptr || bytes_per_sample(encoding) == 0)
+	return "";
+    if (encoding == SORA_ENC_SC16)
+	return "adsb_scan_kernel<true>";
+    return ctx->scan_variant == 1? "adsb_scan_direct_kernel<256>" :
+	    ctx->scan_variant == 2? "adsb_scan_direct_kernel<512>" : "adsb_scan_kernel<false>";
 }
 
 extern "C" int

@@ -74,11 +74,11 @@ struct sora_resolve_args {
 };
 
 /* tiles (workgroup passes) a chunk of n_scan positions needs */
-uint64_t sora_scan_tiles(uint64_t n_scan, int encoding);
+uint64_t sora_scan_tiles(uint64_t n_scan, int encoding, int variant);
 /* LDS bytes / thread count of the scan kernel, for documentation and tests */
-uint32_t sora_scan_groups_per_cu(int encoding);
+uint32_t sora_scan_groups_per_cu(int encoding, int variant);
 
-hipError_t sora_launch_scan(const struct sora_scan_args *a, uint32_t groups,
+hipError_t sora_launch_scan(const struct sora_scan_args *a, uint32_t groups, int variant,
 	hipStream_t stream);
 hipError_t sora_launch_fill_u64(uint64_t *dst, uint64_t value, uint64_t n,
 	hipStream_t stream);

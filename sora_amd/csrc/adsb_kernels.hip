@@ -513,6 +513,264 @@ adsb_scan_kernel(sora_scan_args a) {
     }
 }
 
+/*
+ * The 8-bit scan with the magnitudes kept in registers.  Lane l of wave w
+ * loads ITS OWN 64 bytes (lane run 63 w + l of the tile: four 16-byte loads)
+ * and never stores M: the next lane's first four pairs come over DPP
+ * (wave_shl:1), and lane 63 of a wave is a halo lane -- the run it holds is
+ * computed again, completely, by lane 0 of the next wave -- so phases 1-3
+ * need nothing from another wave and no barrier.  What is shared through LDS
+ * is the NU bit arrays (phase 4 reads 240 positions ahead), double-buffered
+ * by tile parity, the hit prefix and the queue: two barriers per tile instead
+ * of four, 22 KB of LDS instead of 53.
+ */
+template <int kThreads> struct direct_geom {
+    static constexpr int waves = kThreads / 64;
+    static constexpr int lanes = 63 * waves;		/* lane runs computed */
+    static constexpr int own = lanes - 8;		/* ... whose positions are emitted */
+    static constexpr int tile_pos = own * SORA_LANE_POS;
+    static constexpr int tile_bytes = (lanes + 1) * 64;	/* with the last wave's halo run */
+};
+
+__device__ __forceinline__ uint32_t
+next_lane(uint32_t v) {
+    /* lane l reads lane l + 1; lane 63 reads 0 */
+    return (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x130, 0xf, 0xf, true);
+}
+
+#ifndef SORA_DIRECT_WAVES
+#define SORA_DIRECT_WAVES 7
+#endif
+template <int kThreads>
+__global__ void __launch_bounds__(kThreads, SORA_DIRECT_WAVES)
+adsb_scan_direct_kernel(sora_scan_args a) {
+    using D = direct_geom<kThreads>;
+    constexpr int kWaves = D::waves;
+    constexpr int kTilePos = D::tile_pos;
+    constexpr int kQueueMax = kTilePos / 2;		/* p and p+1 never both hit */
+    constexpr int kWords = (D::lanes + 2) / 2 + 1;
+    constexpr int kTabWords = SORA_CRC_TABLE_WORDS + SORA_FIX_TABLE_WORDS;
+
+    /* [tile parity][even, odd positions]: 16-bit halves (one per lane run),
+     * read as 32-bit words */
+    __shared__ __attribute__((aligned(4))) uint16_t s_bits[2][2][2 * kWords];
+    __shared__ __attribute__((aligned(16))) uint32_t s_tab[kTabWords];
+    __shared__ uint16_t s_queue[kQueueMax];
+    __shared__ uint32_t s_cum[2][kWaves + 1];	/* by tile parity, see below */
+    __shared__ uint32_t s_sq_total;
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63, wave = tid >> 6;
+    const uint32_t group = blockIdx.x, groups = gridDim.x;
+    const uint32_t flip = a.encoding == SORA_ENC_UC8? 0x80808080u : 0u;
+    const uint64_t tile_begin = a.n_tiles * group / groups;
+    const uint64_t tile_end = a.n_tiles * (group + 1) / groups;
+
+    uint64_t *rec_out = a.rec + (uint64_t) group * a.rec_cap;
+    uint64_t *sq_out = a.sq + (uint64_t) group * a.sq_cap;
+    uint32_t n_rec = 0;
+    uint32_t st_cand = 0, st_sq = 0, st_dirty = 0, st_fixed = 0;
+
+    {
+	const u32x4 *src = reinterpret_cast<const u32x4 *>(g_crc_slices.w);
+	for (uint32_t c = tid; c < (uint32_t) kTabWords / 4; c += kThreads)
+	    *reinterpret_cast<u32x4 *>(&s_tab[4 * c]) = src[c];
+	if (tid <= (uint32_t) kWaves)
+	    s_cum[0][tid] = s_cum[1][tid] = 0;
+	if (tid == 0)
+	    s_sq_total = 0;
+    }
+    __syncthreads();
+
+    /* the 64 bytes of lane run g of a tile: four 16-byte loads */
+    auto load_run = [&](u32x4 *v, uint64_t tile_no, uint32_t g) {
+	const uint64_t start = tile_no * kTilePos;
+	uint64_t left = (a.n_samples - start) * 2;
+	left = (left + 3) & ~3ull;
+	const uint32_t span = left < (uint64_t) D::tile_bytes?
+		(uint32_t) left : (uint32_t) D::tile_bytes;
+	auto rsrc = __builtin_amdgcn_make_buffer_rsrc(
+		const_cast<uint8_t *>(a.iq) + start * 2, 0, span, 0x00020000);
+#pragma unroll
+	for (int r = 0; r < 4; r++)
+	    v[r] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, g * 64, r * 16, 0);
+    };
+#ifdef SORA_DIRECT_PREFETCH
+    u32x4 v[4];
+#endif
+
+    for (uint64_t tile = tile_begin; tile < tile_end; tile++) {
+	const uint64_t tile_start = tile * kTilePos;
+	const uint32_t par = (uint32_t) (tile - tile_begin) & 1;
+	/* lane run of this lane, opaque per tile (see adsb_scan_kernel) */
+	uint32_t g = 63 * wave + lane;
+	asm volatile("" : "+v"(g));
+
+	/* ---- phase 1: this lane's 64 bytes, magnitudes in registers ---- */
+	uint32_t P[SORA_LANE_PAIRS + 4];
+	{
+#ifdef SORA_DIRECT_PREFETCH
+	    /* the loads were issued a tile ahead */
+	    if (tile == tile_begin)
+		load_run(v, tile, g);
+#else
+	    u32x4 v[4];
+	    load_run(v, tile, g);
+#endif
+#pragma unroll
+	    for (int r = 0; r < 4; r++) {
+		const uint32_t raw[4] = {v[r][0], v[r][1], v[r][2], v[r][3]};
+		sora_mag2_pack8x4(raw, flip, &P[4 * r]);
+	    }
+#ifdef SORA_DIRECT_PREFETCH
+	    if (tile + 1 < tile_end)
+		load_run(v, tile + 1, g);
+#endif
+#pragma unroll
+	    for (int i = 0; i < 4; i++)
+		P[16 + i] = next_lane(P[i]);
+	}
+
+	/* ---- phase 2: compare bits of this lane's 32 positions ---- */
+	uint32_t up, down, cc;
+	sora_lane_compare(P, &up, &down, &cc);
+	const uint32_t nu = ~up;
+	uint16_t *const s_nue = s_bits[par][0], *const s_nuo = s_bits[par][1];
+	if (lane != 63) {		/* the halo lane's run belongs to the next wave */
+	    s_nue[g ^ 1] = (uint16_t) (nu & 0xffffu);
+	    s_nuo[g ^ 1] = (uint16_t) (nu >> 16);
+	}
+
+	/* ---- phase 3: predicate words, ordered queue of hits ---- */
+	uint32_t pe, po;
+	{
+	    const uint64_t left = a.n_scan - tile_start;
+	    const uint32_t nu_next = next_lane(nu), down_next = next_lane(down);
+	    /* own 16 elements above the next lane's 16 (the halo lane's first
+	     * elements are complete: they need none of ITS lookahead) */
+	    sora_lane_predicate(__builtin_amdgcn_perm(nu, nu_next, 0x05040100u),
+		    __builtin_amdgcn_perm(nu, nu_next, 0x07060302u),
+		    __builtin_amdgcn_perm(down, down_next, 0x05040100u),
+		    __builtin_amdgcn_perm(down, down_next, 0x07060302u),
+		    cc << 16, cc & 0xffff0000u, &pe, &po);
+	    if (left >= (uint64_t) kTilePos) {	/* all but the last tile */
+		if (g >= (uint32_t) D::own)
+		    pe = po = 0;
+	    } else {
+		uint32_t ve, vo;
+		sora_lane_valid_n((int) g, (int64_t) left, D::own, &ve, &vo);
+		pe &= ve;
+		po &= vo;
+	    }
+	    if (lane == 63)
+		pe = po = 0;
+	}
+	const uint32_t cnt = __popc(pe | po);
+	const uint32_t incl = wave_inclusive_scan(cnt);
+	{
+	    const uint32_t wave_hits = (uint32_t) __builtin_amdgcn_readlane((int) incl, 63);
+	    if (lane > wave && lane <= (uint32_t) kWaves)
+		atomicAdd(&s_cum[par][lane], wave_hits);
+	}
+	lds_barrier();			/* A: every wave is done with the previous tile */
+	const uint32_t total = s_cum[par][kWaves];
+	uint32_t off = s_cum[par][wave] + incl - cnt;
+	/* the other parity's prefix is used next by the following tile's atomics,
+	 * which no wave reaches before barrier B */
+	if (tid <= (uint32_t) kWaves)
+	    s_cum[par ^ 1][tid] = 0;
+	{
+	    uint32_t both = pe | po;
+	    while (both != 0) {
+		const uint32_t b = __clz(both);
+		const uint32_t twice = __builtin_amdgcn_alignbit(b, po << b, 31);
+		s_queue[off++] = (uint16_t) (g * SORA_LANE_POS | twice);
+		both &= ~(0x80000000u >> b);
+	    }
+	}
+	lds_barrier();			/* B */
+
+	/* ---- phase 4: one lane per candidate (as adsb_scan_kernel) ---- */
+	const uint32_t *w_nue = reinterpret_cast<const uint32_t *>(s_nue);
+	const uint32_t *w_nuo = reinterpret_cast<const uint32_t *>(s_nuo);
+	st_cand += total;
+	for (uint32_t base = 0; base < total; base += kThreads) {
+	    const uint32_t i = base + tid;
+
+	    if (i < total) {
+		uint32_t q = s_queue[i];
+		const uint32_t *words = (q & 1)? w_nuo : w_nue;
+		uint32_t bits[4];
+		sora_candidate c;
+
+		sora_extract_bits(words, (q >> 1) + 8, bits);
+		sora_classify(bits, s_tab, &c);
+		uint64_t kind = !c.squitter? SORA_REC_KIND_REPLY :
+			c.syndrome == 0? SORA_REC_KIND_SQUITTER : SORA_REC_KIND_DIRTY;
+		uint32_t payload = kind == SORA_REC_KIND_DIRTY? c.syndrome : c.address;
+		if (a.correct && kind == SORA_REC_KIND_DIRTY) {
+		    const int b = sora_fix_bit(c.syndrome, c.is_long? 112 : 56,
+			    s_tab + SORA_CRC_TABLE_WORDS);
+		    if (b >= 0) {
+			kind = SORA_REC_KIND_CORRECTED;
+			payload = c.address;
+			if (b >= 8 && b < 32)
+			    payload ^= 1u << (31 - b);
+		    }
+		}
+		const uint32_t rec_lo = (q << 24) | payload;
+		const uint32_t rec_hi = (q >> 8) | ((uint32_t) kind << 28);
+		const uint64_t record = (tile_start << 24) +
+			(((uint64_t) rec_hi << 32) | rec_lo);
+		const uint32_t idx = n_rec + i;
+		if (idx < a.rec_cap)
+		    rec_out[idx] = record;
+		if (kind == SORA_REC_KIND_SQUITTER || kind == SORA_REC_KIND_CORRECTED) {
+		    const uint32_t k = atomicAdd(&s_sq_total, 1u);
+		    if (k < a.sq_cap)
+			sq_out[k] = record;
+		}
+		st_sq += (uint32_t) __popcll(__ballot(kind == SORA_REC_KIND_SQUITTER));
+		st_dirty += (uint32_t) __popcll(__ballot(kind == SORA_REC_KIND_DIRTY));
+		if (a.correct)
+		    st_fixed += (uint32_t) __popcll(__ballot(kind == SORA_REC_KIND_CORRECTED));
+	    }
+	}
+	n_rec += total;
+	/* the next tile writes the other parity's NU arrays and prefix; its queue
+	 * writes come behind its barrier A */
+    }
+
+    lds_barrier();			/* the last tile's squitter appends */
+    if (tid == 0) {
+	a.rec_count[group] = n_rec;
+	a.sq_count[group] = s_sq_total;
+    }
+    {
+	__shared__ uint32_t s_stat[kWaves][3];
+	if (lane == 0) {
+	    s_stat[wave][0] = st_sq;
+	    s_stat[wave][1] = st_dirty;
+	    s_stat[wave][2] = st_fixed;
+	}
+	__syncthreads();
+	if (tid == 0) {
+	    uint64_t t1 = 0, t2 = 0, t3 = 0;
+	    for (int w = 0; w < kWaves; w++) {
+		t1 += s_stat[w][0];
+		t2 += s_stat[w][1];
+		t3 += s_stat[w][2];
+	    }
+	    uint64_t *st = a.stats + (uint64_t) group * SORA_STAT_WORDS;
+	    st[SORA_STAT_CANDIDATES] = st_cand;
+	    st[SORA_STAT_SQUITTERS] = t1;
+	    st[SORA_STAT_DIRTY] = t2;
+	    st[SORA_STAT_REPLIES] = st_cand - t1 - t2 - t3;
+	    st[SORA_STAT_CORRECTED] = t3;
+	}
+    }
+}
+
 /* ------------------------------------------------------- small kernels -- */
 
 __global__ void
@@ -1078,14 +1336,22 @@ grid_for(uint64_t n, uint32_t block) {
 /* ---------------------------------------------------------- launchers -- */
 
 uint64_t
-sora_scan_tiles(uint64_t n_scan, int encoding) {
-    const uint64_t pos = encoding == SORA_ENC_SC16? SORA16_TILE_POS : SORA_TILE_POS;
+sora_scan_tiles(uint64_t n_scan, int encoding, int variant) {
+    uint64_t pos = encoding == SORA_ENC_SC16? SORA16_TILE_POS : SORA_TILE_POS;
+    if (encoding != SORA_ENC_SC16 && variant == 1)
+	pos = direct_geom<256>::tile_pos;
+    if (encoding != SORA_ENC_SC16 && variant == 2)
+	pos = direct_geom<512>::tile_pos;
     return (n_scan + pos - 1) / pos;
 }
 
 uint32_t
-sora_scan_groups_per_cu(int encoding) {
-    /* workgroups of one CU: bounded by LDS (45 KB and 39 KB per workgroup) */
+sora_scan_groups_per_cu(int encoding, int variant) {
+    if (encoding != SORA_ENC_SC16 && variant == 1)
+	return SORA_DIRECT_WAVES;	/* 256 threads: as many workgroups as waves per SIMD */
+    if (encoding != SORA_ENC_SC16 && variant == 2)
+	return 3;
+    /* workgroups of one CU: bounded by LDS (53 KB and 39 KB per workgroup) */
 #ifdef SORA_GROUPS_PER_CU
     return encoding == SORA_ENC_SC16? 4 : SORA_GROUPS_PER_CU;
 #else
@@ -1094,7 +1360,17 @@ sora_scan_groups_per_cu(int encoding) {
 }
 
 hipError_t
-sora_launch_scan(const sora_scan_args *a, uint32_t groups, hipStream_t stream) {
+sora_launch_scan(const sora_scan_args *a, uint32_t groups, int variant, hipStream_t stream) {
+    if (a->encoding != SORA_ENC_SC16 && (variant == 1 || variant == 2)) {
+	(void) hipGetLastError();
+	if (variant == 1)
+	    hipLaunchKernelGGL(adsb_scan_direct_kernel<256>, dim3(groups), dim3(256), 0,
+		    stream, *a);
+	else
+	    hipLaunchKernelGGL(adsb_scan_direct_kernel<512>, dim3(groups), dim3(512), 0,
+		    stream, *a);
+	return hipGetLastError();
+    }
     switch (a->encoding) {
     case SORA_ENC_UC8:
     case SORA_ENC_SC8:

@@ -599,3 +599,66 @@ def test_workgroup_ranges_do_not_matter(monkeypatch, min_tiles, rounds):
     raw = synth.fill_host(p16.n_samples, ENC_SC16, p16.seed, synth.make_frames(p16)).tobytes()
     got, _ = gpu_frames(raw, ENC_SC16)
     assert_same_frames(got, ob.scan(raw, ENC_SC16))
+
+
+# ---- the three 8-bit scan kernels (SORA_ADSB_SCAN_VARIANT: 0 magnitudes through
+# LDS, 16128-position tiles; 1 and 2 magnitudes in registers, 7808- and
+# 15872-position tiles) give the same list on the same input.
+SCAN_TILE_POS = {0: 16128, 1: 7808, 2: 15872}
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2])
+def test_scan_variants_tile_edges_and_ragged_ends(monkeypatch, variant):
+    monkeypatch.setenv("SORA_ADSB_SCAN_VARIANT", str(variant))
+    monkeypatch.setenv("SORA_ADSB_SCAN_MIN_TILES", "2")
+    with AdsbContext(1024) as ctx:
+        assert ctx.scan_kernel_name(ENC_UC8) == ["adsb_scan_kernel<false>",
+                                                 "adsb_scan_direct_kernel<256>",
+                                                 "adsb_scan_direct_kernel<512>"][variant]
+    klm = synth.hex_to_bits("8D4840D6202CC371C32CE0576098")
+    T = SCAN_TILE_POS[variant]
+    # frames that start just before, on and just after tile edges and the edges
+    # of a wave's 63 lane runs (2016 positions) inside a tile
+    edges = [T - 241, T + 1, 2 * T - 17, 2 * T + 2016 - 240, 3 * T + 2016 - 1,
+             3 * T + 2 * 2016, 4 * T - 239, 5 * T + 31, 5 * T + 32 + 2016, 6 * T - 64,
+             7 * T - 1, 8 * T]
+    table = synth.frame_table([(p, klm, 70, 0, 112) for p in edges])
+    for n in (8 * T + 239, 8 * T + 240, 8 * T + 241, 9 * T - 1, 9 * T, 9 * T + 1,
+              9 * T - 1 + 240, 9 * T + 500):
+        raw = synth.fill_host(n, ENC_UC8, 99, table).tobytes()
+        want = ob.scan(raw)
+        got, counts = gpu_frames(raw)
+        assert_same_frames(got, want)
+        assert counts["candidates"] == len(want)
+    assert set(edges) <= {c["position"] for c in got if c["accepted"]}
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("enc", [ENC_UC8, ENC_SC8])
+def test_scan_variants_noise_dense_hits_and_correction(monkeypatch, variant, enc):
+    monkeypatch.setenv("SORA_ADSB_SCAN_VARIANT", str(variant))
+    rng = np.random.default_rng(1000 + variant)
+    raw = rng.integers(0, 256, size=2 * 200003, dtype=np.uint8).tobytes()
+    got, _ = gpu_frames(raw, enc)
+    assert_same_frames(got, ob.scan(raw, enc))
+    if enc != ENC_UC8:
+        return
+    # a preamble every 20 samples: hits in every lane run
+    p = synth.default_params(2, n_samples=150000, mean_gap=20, reply_permille=500,
+                             unknown_permille=300, n_icao=9, seed=12)
+    raw = synth.fill_host(p.n_samples, p.encoding, p.seed, synth.make_frames(p)).tobytes()
+    want = ob.scan(raw)
+    got, counts = gpu_frames(raw)
+    assert_same_frames(got, want)
+    assert counts["candidates"] == len(want)
+    # single-bit correction (parity unpinned, see above) in each kernel's phase 4
+    p = synth.default_params(4, n_samples=600000, seed=13)     # 20 % flipped-bit frames
+    p.encoding = ENC_UC8
+    p.amp_min, p.amp_max = 30, 110
+    raw = synth.fill_host(p.n_samples, p.encoding, p.seed, synth.make_frames(p)).tobytes()
+    want = ob.scan(raw, correct=True)
+    n_fixed = sum(1 for c in want if c["corrected_bit"] >= 0)
+    assert n_fixed > 30
+    got, counts = gpu_frames(raw, correct_single_bit=True)
+    assert_same_frames(got, want)
+    assert counts["corrected"] == n_fixed
