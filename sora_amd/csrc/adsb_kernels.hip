@@ -705,21 +705,22 @@ adsb_scan_direct_kernel(sora_scan_args a) {
 
 		sora_extract_bits(words, (q >> 1) + 8, bits);
 		sora_classify(bits, s_tab, &c);
-		uint64_t kind = !c.squitter? SORA_REC_KIND_REPLY :
-			c.syndrome == 0? SORA_REC_KIND_SQUITTER : SORA_REC_KIND_DIRTY;
+		uint32_t kind = !c.squitter? (uint32_t) SORA_REC_KIND_REPLY :
+			c.syndrome == 0? (uint32_t) SORA_REC_KIND_SQUITTER :
+			(uint32_t) SORA_REC_KIND_DIRTY;
 		uint32_t payload = kind == SORA_REC_KIND_DIRTY? c.syndrome : c.address;
 		if (a.correct && kind == SORA_REC_KIND_DIRTY) {
 		    const int b = sora_fix_bit(c.syndrome, c.is_long? 112 : 56,
 			    s_tab + SORA_CRC_TABLE_WORDS);
 		    if (b >= 0) {
-			kind = SORA_REC_KIND_CORRECTED;
+			kind = (uint32_t) SORA_REC_KIND_CORRECTED;
 			payload = c.address;
 			if (b >= 8 && b < 32)
 			    payload ^= 1u << (31 - b);
 		    }
 		}
 		const uint32_t rec_lo = (q << 24) | payload;
-		const uint32_t rec_hi = (q >> 8) | ((uint32_t) kind << 28);
+		const uint32_t rec_hi = (q >> 8) | (kind << 28);
 		const uint64_t record = (tile_start << 24) +
 			(((uint64_t) rec_hi << 32) | rec_lo);
 		const uint32_t idx = n_rec + i;
@@ -805,7 +806,9 @@ note_known(uint64_t *first_seen, uint32_t *known_bits, uint32_t addr,
     }
 }
 
-/* one block per workgroup region of the scan */
+/* one block per workgroup region of the scan (one wave per region, several
+ * regions per wave, measured slower: 0.082 -> 0.107 ms, the kernel waits for the
+ * few hundred hot lines of first_seen, not for block starts) */
 __global__ void
 first_seen_kernel(sora_resolve_args a) {
     const uint32_t group = blockIdx.x;
@@ -856,40 +859,76 @@ add_known_blocks_kernel(uint64_t *first_seen, uint32_t *known_bits,
     }
 }
 
-/* offsets[i] = sum_{j<i} min(counts[j], cap); offsets[n] = total.  One block:
- * every thread sums a run of consecutive counts, the block scans the 1024
- * sums, every thread writes its run's offsets. */
+/* offsets[i] = sum_{j<i} min(counts[j], cap); offsets[n] = total.  One block
+ * of 16 waves: a wave takes a contiguous sixteenth of the counts in chunks of
+ * 64 (coalesced loads and stores), sums it, the block adds up the waves, and
+ * the wave goes over its chunks again (they are in L2) with a running base and
+ * one wave scan per chunk.  kNarrow: 64 * cap < 2^32, a chunk's prefix sums fit 32 bits
+ * and take the DPP scan (a dependent chain of 64-bit shuffles per chunk was
+ * what the kernel spent its time on). */
+template <bool kNarrow>
 __global__ void __launch_bounds__(1024)
 scan_counts_kernel(const uint32_t *counts, uint32_t cap, uint64_t *offsets,
 	uint32_t n) {
     __shared__ uint64_t s_wave[16];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t per = (n + 1023) / 1024;
-    const uint32_t begin = tid * per < n? tid * per : n;
+    const uint32_t per = ((n + 1023) / 1024) * 64;	/* counts per wave */
+    const uint32_t begin = wave * per < n? wave * per : n;
     const uint32_t end = begin + per < n? begin + per : n;
 
+    constexpr int kUnroll = 8;		/* chunk loads in flight */
     uint64_t sum = 0;
-    for (uint32_t i = begin; i < end; i++)
-	sum += counts[i] < cap? counts[i] : cap;
-    uint64_t incl = sum;
+    for (uint32_t first = begin; first < end; first += 64 * kUnroll) {
+	uint32_t c[kUnroll];
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-	uint64_t o = __shfl_up(incl, d, 64);
-	if (lane >= (uint32_t) d)
-	    incl += o;
+	for (int u = 0; u < kUnroll; u++) {
+	    const uint32_t i = first + u * 64 + lane;
+	    c[u] = i < end? counts[i] : 0;
+	}
+#pragma unroll
+	for (int u = 0; u < kUnroll; u++)
+	    sum += c[u] < cap? c[u] : cap;
     }
-    if (lane == 63)
-	s_wave[wave] = incl;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1)
+	sum += __shfl_xor(sum, d, 64);
+    if (lane == 0)
+	s_wave[wave] = sum;
     __syncthreads();
-    uint64_t pre = incl - sum;
+    uint64_t base = 0;
     for (uint32_t w = 0; w < wave; w++)
-	pre += s_wave[w];
-    for (uint32_t i = begin; i < end; i++) {
-	offsets[i] = pre;
-	pre += counts[i] < cap? counts[i] : cap;
+	base += s_wave[w];
+    for (uint32_t first = begin; first < end; first += 64 * kUnroll) {
+	uint32_t c[kUnroll];
+#pragma unroll
+	for (int u = 0; u < kUnroll; u++) {
+	    const uint32_t i = first + u * 64 + lane;
+	    c[u] = i < end? counts[i] : 0;
+	    c[u] = c[u] < cap? c[u] : cap;
+	}
+#pragma unroll
+	for (int u = 0; u < kUnroll; u++) {
+	    const uint32_t i = first + u * 64 + lane;
+	    uint64_t incl;
+	    if constexpr (kNarrow) {
+		incl = wave_inclusive_scan(c[u]);
+	    } else {
+		incl = c[u];
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) {
+		    const uint64_t o = __shfl_up(incl, d, 64);
+		    if (lane >= (uint32_t) d)
+			incl += o;
+		}
+	    }
+	    if (i < end)
+		offsets[i] = base + incl - c[u];
+	    base += kNarrow? (uint64_t) (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) incl, 63) :
+		    __shfl(incl, 63, 64);
+	}
     }
     if (tid == 1023)
-	offsets[n] = pre;
+	offsets[n] = base;	/* the last wave's base has passed every count */
 }
 
 /*
@@ -1434,8 +1473,12 @@ hipError_t
 sora_launch_scan_counts(const uint32_t *counts, uint32_t cap,
 	uint64_t *offsets, uint32_t n, hipStream_t stream) {
     (void) hipGetLastError();
-    hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream,
-	    counts, cap, offsets, n);
+    if (cap < (1u << 26))
+	hipLaunchKernelGGL(scan_counts_kernel<true>, dim3(1), dim3(1024), 0, stream,
+		counts, cap, offsets, n);
+    else
+	hipLaunchKernelGGL(scan_counts_kernel<false>, dim3(1), dim3(1024), 0, stream,
+		counts, cap, offsets, n);
     return hipGetLastError();
 }
 
