@@ -541,6 +541,19 @@ next_lane(uint32_t v) {
 #ifndef SORA_DIRECT_WAVES
 #define SORA_DIRECT_WAVES 7
 #endif
+/* cache policy of the record stores and of the sample loads (experiments) */
+#if defined(SORA_PROBE_REC_WINDOW)
+/* timing probe only: every record store lands in a 512 KB window that stays in
+ * L2 (wrong results) -- separates the store path from the HBM write traffic */
+#define SORA_REC_STORE(p, v) (a.rec[(((p) - a.rec) & 255) + 256 * (blockIdx.x & 255)] = (v))
+#elif defined(SORA_NT_STORE)
+#define SORA_REC_STORE(p, v) __builtin_nontemporal_store((v), (p))
+#else
+#define SORA_REC_STORE(p, v) (*(p) = (v))
+#endif
+#ifndef SORA_LOAD_AUX
+#define SORA_LOAD_AUX 0
+#endif
 template <int kThreads>
 __global__ void __launch_bounds__(kThreads, SORA_DIRECT_WAVES)
 adsb_scan_direct_kernel(sora_scan_args a) {
@@ -593,7 +606,7 @@ adsb_scan_direct_kernel(sora_scan_args a) {
 		const_cast<uint8_t *>(a.iq) + start * 2, 0, span, 0x00020000);
 #pragma unroll
 	for (int r = 0; r < 4; r++)
-	    v[r] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, g * 64, r * 16, 0);
+	    v[r] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, g * 64, r * 16, SORA_LOAD_AUX);
     };
 #ifdef SORA_DIRECT_PREFETCH
     u32x4 v[4];
@@ -725,7 +738,7 @@ adsb_scan_direct_kernel(sora_scan_args a) {
 			(((uint64_t) rec_hi << 32) | rec_lo);
 		const uint32_t idx = n_rec + i;
 		if (idx < a.rec_cap)
-		    rec_out[idx] = record;
+		    SORA_REC_STORE(&rec_out[idx], record);
 		if (kind == SORA_REC_KIND_SQUITTER || kind == SORA_REC_KIND_CORRECTED) {
 		    const uint32_t k = atomicAdd(&s_sq_total, 1u);
 		    if (k < a.sq_cap)

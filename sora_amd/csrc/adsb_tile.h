@@ -8,6 +8,9 @@
  *   M[i]      integer squared magnitude of sample i, I^2+Q^2 in counts.  For
  *             uc8/sc8 the reference's float m[i] is exactly M[i] * 2^-14
  *             (plane-iq.c:132-135), so integer compares equal float compares.
+ *   M'[i]     what the 8-bit kernels hold in registers: M[i] - 32768 as a
+ *             signed 16-bit half (M <= 32768, so M' is in [-32768, 0]): the
+ *             order is the same, and differences saturate instead of wrapping
  *   pair j    samples 2j (low half of a dword) and 2j+1 (high half)
  *   NU[i]     "not up": M[i+1] <= M[i].  This IS the PPM bit the slicer
  *             assigns (plane-iq.c:65); bit k of a candidate at p is
@@ -112,45 +115,46 @@ sora_mag2_pack8(uint32_t iq, uint32_t flip) {
     uint32_t m0 = (uint32_t) (i0 * i0 + q0 * q0);
     uint32_t m1 = (uint32_t) (i1 * i1 + q1 * q1);
 #endif
-    return m0 | (m1 << 16);		/* each <= 32768 */
+    /* each <= 32768; biased to signed halves */
+    return ((m0 - 0x8000u) & 0xffffu) | ((m1 - 0x8000u) << 16);
 }
 
 /*
- * Four dwords (eight samples) at once, the form the scan kernel uses.  Per
- * dword x (after the flip): T = dot4(x, x) = M0 + M1, H = dot4(x, x with its
- * low half cleared) = M1, packed = T + 65535 * H = M0 + 65536 * M1: five VALU
- * instructions per dword.  The dot products are written as the VOP3P
- * v_dot4_i32_i8 with an inline 0 accumulator (the builtin picks the
- * accumulating VOP2 form and pays a v_mov 0 each).  gfx90a+ does not
- * interlock a dot result against the next VALU instructions (LLVM inserts
- * 3 wait states for its own dots, DotWriteDifferentVALURead); inside this
- * block every result is read at least 3 instructions, and overwritten at
- * least 4 instructions, after the dot that wrote it.
+ * Four dwords (eight samples) at once, the form the scan kernels use.  Per
+ * dword x (after the flip): M0 - 32768 = dot4(x with its high half cleared,
+ * the same) - 32768 and M1 - 32768 likewise from the high half -- the bias is
+ * the dot product's accumulator operand -- and one v_perm_b32 puts the two low
+ * halves side by side: two v_bitop3 ((v ^ flip) & mask), two dots and the
+ * permute, five VALU instructions per dword.  The dot products are written as
+ * the VOP3P v_dot4_i32_i8 in one asm block.  gfx90a+ does not interlock a dot
+ * result against the next VALU instructions (LLVM inserts 3 wait states for
+ * its own dots, DotWriteDifferentVALURead); inside this block every result is
+ * read at least 3 instructions after the dot that wrote it.
  */
 SORA_HD void
 sora_mag2_pack8x4(const uint32_t v[4], uint32_t flip, uint32_t m[4]) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    const uint32_t x0 = v[0] ^ flip, x1 = v[1] ^ flip, x2 = v[2] ^ flip,
-	    x3 = v[3] ^ flip;
-    const uint32_t h0 = x0 & 0xffff0000u, h1 = x1 & 0xffff0000u,
-	    h2 = x2 & 0xffff0000u, h3 = x3 & 0xffff0000u;
+    const uint32_t l0 = (v[0] ^ flip) & 0xffffu, l1 = (v[1] ^ flip) & 0xffffu,
+	    l2 = (v[2] ^ flip) & 0xffffu, l3 = (v[3] ^ flip) & 0xffffu;
+    const uint32_t h0 = (v[0] ^ flip) & 0xffff0000u, h1 = (v[1] ^ flip) & 0xffff0000u,
+	    h2 = (v[2] ^ flip) & 0xffff0000u, h3 = (v[3] ^ flip) & 0xffff0000u;
     uint32_t t0, t1, t2, t3, g0, g1, g2, g3;
-    asm("v_dot4_i32_i8 %0, %8, %8, 0\n\t"
-	"v_dot4_i32_i8 %4, %8, %12, 0\n\t"
-	"v_dot4_i32_i8 %1, %9, %9, 0\n\t"
-	"v_dot4_i32_i8 %5, %9, %13, 0\n\t"
-	"v_dot4_i32_i8 %2, %10, %10, 0\n\t"
-	"v_dot4_i32_i8 %6, %10, %14, 0\n\t"
-	"v_dot4_i32_i8 %3, %11, %11, 0\n\t"
-	"v_dot4_i32_i8 %7, %11, %15, 0\n\t"
-	"v_mad_u32_u24 %0, %4, %16, %0\n\t"
-	"v_mad_u32_u24 %1, %5, %16, %1\n\t"
-	"v_mad_u32_u24 %2, %6, %16, %2\n\t"
-	"v_mad_u32_u24 %3, %7, %16, %3"
+    asm("v_dot4_i32_i8 %0, %8, %8, %16\n\t"
+	"v_dot4_i32_i8 %4, %12, %12, %16\n\t"
+	"v_dot4_i32_i8 %1, %9, %9, %16\n\t"
+	"v_dot4_i32_i8 %5, %13, %13, %16\n\t"
+	"v_dot4_i32_i8 %2, %10, %10, %16\n\t"
+	"v_dot4_i32_i8 %6, %14, %14, %16\n\t"
+	"v_dot4_i32_i8 %3, %11, %11, %16\n\t"
+	"v_dot4_i32_i8 %7, %15, %15, %16\n\t"
+	"v_perm_b32 %0, %4, %0, %17\n\t"
+	"v_perm_b32 %1, %5, %1, %17\n\t"
+	"v_perm_b32 %2, %6, %2, %17\n\t"
+	"v_perm_b32 %3, %7, %3, %17"
 	: "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3),
 	  "=&v"(g0), "=&v"(g1), "=&v"(g2), "=&v"(g3)
-	: "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(h0), "v"(h1), "v"(h2), "v"(h3),
-	  "s"(0xffffu));
+	: "v"(l0), "v"(l1), "v"(l2), "v"(l3), "v"(h0), "v"(h1), "v"(h2), "v"(h3),
+	  "s"(0xffff8000u), "s"(0x05040100u));
     m[0] = t0; m[1] = t1; m[2] = t2; m[3] = t3;
 #else
     for (int i = 0; i < 4; i++)
@@ -211,53 +215,74 @@ sora_mag_sc16x4(const uint32_t v[4], uint32_t m[4]) {
 
 /* ---- packed 16-bit arithmetic: one VALU instruction per pair on gfx950 ---- */
 
-/* acc | (v << sh): one v_lshl_or_b32 (left alone, the compiler re-associates a
- * run of these into shift + shift + v_or3, three instructions per two bits) */
+/* per half, signed: a - b, saturating at -32768 / 32767 (v_pk_sub_i16 ... clamp;
+ * the saturation is on the exact difference, tools/probe/pk_i16_probe.cpp) */
 SORA_HD uint32_t
-sora_shl_or(uint32_t v, int sh, uint32_t acc) {
+sora_pk_sub_i16_sat(uint32_t a, uint32_t b) {
 #if defined(__HIP_DEVICE_COMPILE__)
     uint32_t r;
-    asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "n"(sh), "v"(acc));
+    asm("v_pk_sub_i16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
     return r;
 #else
-    return acc | (v << sh);
+    uint32_t r = 0;
+    for (int h = 0; h < 2; h++) {
+	int32_t d = (int32_t) (int16_t) (a >> (16 * h)) - (int32_t) (int16_t) (b >> (16 * h));
+	d = d > 32767? 32767 : d < -32768? -32768 : d;
+	r |= ((uint32_t) d & 0xffffu) << (16 * h);
+    }
+    return r;
 #endif
 }
 
-/* per half: a - b, saturating at 0 (v_pk_sub_u16 ... clamp) */
+/*
+ * per half: the sign of w as a bit pattern -- 0x8000 if w > 0, 0x7fff if
+ * w < 0, 0 if w == 0: w * -32768 saturated to 16 bits (v_pk_mad_i16 ... clamp).
+ * Bits 0..14 say "negative", bit 15 says "positive"; applied twice it swaps
+ * the two.
+ */
 SORA_HD uint32_t
-sora_pk_sub_sat(uint32_t a, uint32_t b) {
+sora_pk_sign_pattern(uint32_t w) {
 #if defined(__HIP_DEVICE_COMPILE__)
     uint32_t r;
-    asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    asm("v_pk_mad_i16 %0, %1, %2, 0 clamp" : "=v"(r) : "v"(w), "s"(0x80008000u));
     return r;
 #else
-    uint32_t al = a & 0xffffu, ah = a >> 16, bl = b & 0xffffu, bh = b >> 16;
-    return (al > bl? al - bl : 0) | ((ah > bh? ah - bh : 0) << 16);
+    uint32_t r = 0;
+    for (int h = 0; h < 2; h++) {
+	const int32_t x = (int16_t) (w >> (16 * h));
+	r |= (x > 0? 0x8000u : x < 0? 0x7fffu : 0u) << (16 * h);
+    }
+    return r;
 #endif
 }
 
+/* per half, signed maximum (v_pk_max_i16) */
 SORA_HD uint32_t
-sora_pk_min(uint32_t a, uint32_t b) {
+sora_pk_max_i16(uint32_t a, uint32_t b) {
 #if defined(__HIP_DEVICE_COMPILE__)
     uint32_t r;
-    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    asm("v_pk_max_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 #else
-    uint32_t al = a & 0xffffu, ah = a >> 16, bl = b & 0xffffu, bh = b >> 16;
-    return (al < bl? al : bl) | ((ah < bh? ah : bh) << 16);
+    uint32_t r = 0;
+    for (int h = 0; h < 2; h++) {
+	const int16_t x = (int16_t) (a >> (16 * h)), y = (int16_t) (b >> (16 * h));
+	r |= ((uint32_t) (uint16_t) (x > y? x : y)) << (16 * h);
+    }
+    return r;
 #endif
 }
 
+/* acc | (x & mask): one v_and_or_b32 (kept as asm so that the compiler does not
+ * re-associate a chain of them) */
 SORA_HD uint32_t
-sora_pk_max(uint32_t a, uint32_t b) {
+sora_and_or(uint32_t x, uint32_t mask, uint32_t acc) {
 #if defined(__HIP_DEVICE_COMPILE__)
     uint32_t r;
-    asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "s"(mask), "v"(acc));
     return r;
 #else
-    uint32_t al = a & 0xffffu, ah = a >> 16, bl = b & 0xffffu, bh = b >> 16;
-    return (al > bl? al : bl) | ((ah > bh? ah : bh) << 16);
+    return acc | (x & mask);
 #endif
 }
 
@@ -274,17 +299,20 @@ sora_pair_shift(uint32_t p, uint32_t pn) {
 /* ---- a3/a5 on one lane's run of 16 pairs ---- */
 
 /*
- * P[0..19]: the lane's 16 dwords of packed M followed by the next lane's
+ * P[0..19]: the lane's 16 dwords of packed M' followed by the next lane's
  * first 4.  Each result holds the EVEN positions in its low half and the ODD
  * positions in its high half; within a half, pair s of the lane is bit 15-s.
  *   up   M[i+1] >  M[i]		(NU = ~up is the slicer bit, plane-iq.c:65)
  *   down M[i+1] <  M[i]
  *   c    M[i] > max(M[i+4], M[i+5], M[i+6])
- * 12 VALU instructions per pair for both parities.
+ * One saturating difference w = M'[i+1] - M'[i] serves up and down: its sign
+ * pattern x has "down" in bits 0..14 and "up" in bit 15, the pattern of x the
+ * other way round, and v_and_or_b32 picks the pair's bit out of whichever has
+ * it.  Per pair: the shifted pair, two maxima, 5 instructions for up and down,
+ * 3 for c: 11 VALU instructions for both parities.
  */
 SORA_HD void
 sora_lane_compare(const uint32_t *P, uint32_t *up, uint32_t *down, uint32_t *c) {
-    const uint32_t one = 0x00010001u;
     uint32_t S[SORA_LANE_PAIRS + 3];
     uint32_t W[SORA_LANE_PAIRS + 2];
     uint32_t acc_u = 0, acc_d = 0, acc_c = 0;
@@ -294,22 +322,31 @@ sora_lane_compare(const uint32_t *P, uint32_t *up, uint32_t *down, uint32_t *c) 
 #endif
     for (int s = 0; s < SORA_LANE_PAIRS + 3; s++)
 	S[s] = sora_pair_shift(P[s], P[s + 1]);
-    /* W[s] = [max M[2s..2s+2], max M[2s+1..2s+3]] */
+    /* W[s] = [max M'[2s..2s+2], max M'[2s+1..2s+3]] */
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
     for (int s = 2; s < SORA_LANE_PAIRS + 2; s++)
-	W[s] = sora_pk_max(sora_pk_max(P[s], S[s]), P[s + 1]);
+	W[s] = sora_pk_max_i16(sora_pk_max_i16(P[s], S[s]), P[s + 1]);
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
     for (int s = 0; s < SORA_LANE_PAIRS; s++) {
-	uint32_t u = sora_pk_min(sora_pk_sub_sat(S[s], P[s]), one);
-	uint32_t d = sora_pk_min(sora_pk_sub_sat(P[s], S[s]), one);
-	uint32_t k = sora_pk_min(sora_pk_sub_sat(P[s], W[s + 2]), one);
-	acc_u = sora_shl_or(u, 15 - s, acc_u);
-	acc_d = sora_shl_or(d, 15 - s, acc_d);
-	acc_c = sora_shl_or(k, 15 - s, acc_c);
+	const uint32_t mask = 0x00010001u << (15 - s);
+	const uint32_t x = sora_pk_sign_pattern(sora_pk_sub_i16_sat(S[s], P[s]));
+	const uint32_t y = sora_pk_sign_pattern(x);
+
+	if (s == 0) {		/* bit 15: "positive" of x is up, of y is down */
+	    acc_u = sora_and_or(x, mask, acc_u);
+	    acc_d = sora_and_or(y, mask, acc_d);
+	    acc_c = sora_and_or(sora_pk_sign_pattern(sora_pk_sub_i16_sat(P[s], W[s + 2])),
+		    mask, acc_c);
+	} else {		/* bits 0..14: "negative" of x is down, of y is up */
+	    acc_d = sora_and_or(x, mask, acc_d);
+	    acc_u = sora_and_or(y, mask, acc_u);
+	    acc_c = sora_and_or(sora_pk_sign_pattern(sora_pk_sub_i16_sat(W[s + 2], P[s])),
+		    mask, acc_c);
+	}
     }
     *up = acc_u;
     *down = acc_d;
