@@ -1338,6 +1338,8 @@ finalize_kernel(sora_resolve_args a) {
 
     if (total > a.frames_cap)
 	total = a.frames_cap;
+    if (a.n_samples < SORA_WINDOW)
+	total = 0;
     /* a wave takes 64 consecutive frames at a time: one coalesced load brings
      * their records (no dependent record fetch per frame); row g of round i
      * works on frame 4 i + g */
@@ -1350,6 +1352,7 @@ finalize_kernel(sora_resolve_args a) {
 	for (uint32_t j = 0; j < cnt; j += 4 * kFinalizeDepth) {
 	    uint64_t r[kFinalizeDepth];
 	    uint32_t idx[kFinalizeDepth];
+	    bool sane[kFinalizeDepth];
 	    frame_part<kWide> part[kFinalizeDepth];
 #pragma unroll
 	    for (int u = 0; u < kFinalizeDepth; u++) {
@@ -1357,12 +1360,16 @@ finalize_kernel(sora_resolve_args a) {
 		const uint32_t k = idx[u] < cnt? idx[u] : cnt - 1;
 		r[u] = (uint64_t) (uint32_t) __shfl((int) (uint32_t) mine, (int) k, 64) |
 			((uint64_t) (uint32_t) __shfl((int) (uint32_t) (mine >> 32), (int) k, 64) << 32);
-		part[u] = load_frame_part<kWide>(a.iq, sora_rec_pos(r[u]), sub);
+		/* the scan only records p with p + 240 <= n_samples; a record that
+		 * says otherwise is corrupt, and following it would read outside
+		 * the capture: such a frame is left out */
+		sane[u] = sora_rec_pos(r[u]) + SORA_WINDOW <= a.n_samples;
+		part[u] = load_frame_part<kWide>(a.iq, sane[u]? sora_rec_pos(r[u]) : 0, sub);
 	    }
 #pragma unroll
 	    for (int u = 0; u < kFinalizeDepth; u++)
 		if (j + 4 * u < cnt)				/* wave-uniform */
-		    finalize_four<kWide>(a, batch + idx[u], idx[u] < cnt, r[u], part[u],
+		    finalize_four<kWide>(a, batch + idx[u], idx[u] < cnt && sane[u], r[u], part[u],
 			    lane, pw, flip, any_corrected);
 	}
     }
