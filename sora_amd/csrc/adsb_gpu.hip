@@ -342,6 +342,13 @@ sora_adsb_scan(sora_adsb_ctx *ctx, const void *d_iq, size_t nbytes, int encoding
     if (n_tiles / ctx->scan_min_tiles < groups)
 	groups = n_tiles >= ctx->scan_min_tiles? (uint32_t) (n_tiles / ctx->scan_min_tiles) : 1;
 
+    /* a record carries its position relative to the first tile of its
+     * workgroup's range in SORA_REGION_POS_BITS bits */
+    if ((n_tiles / groups + 1) * sora_scan_tile_pos(encoding, (int) ctx->scan_variant) >=
+	    (1ull << SORA_REGION_POS_BITS))
+	return fail(ctx, SORA_ERR_INVALID, "chunk of %llu samples is too long for %u scan regions",
+		(unsigned long long) n_samples, groups);
+
     sora_scan_args &a = ctx->scan;
     memset(&a, 0, sizeof a);
     a.iq = static_cast<const uint8_t *>(d_iq);
@@ -351,7 +358,10 @@ sora_adsb_scan(sora_adsb_ctx *ctx, const void *d_iq, size_t nbytes, int encoding
     a.encoding = encoding;
     a.emit_all = ctx->cfg.emit_mode == SORA_EMIT_CANDIDATES;
     a.correct = (ctx->cfg.options & SORA_OPT_CORRECT_SINGLE_BIT) != 0;
-    a.rec = ctx->d_rec;
+    /* the record buffer holds the 4-byte keys, then the 2-byte tails */
+    a.key = reinterpret_cast<uint32_t *>(ctx->d_rec);
+    a.tail = reinterpret_cast<uint16_t *>(reinterpret_cast<uint32_t *>(ctx->d_rec) +
+	    ctx->rec_total);
     a.sq = ctx->d_sq;
     a.rec_cap = (uint32_t) (ctx->rec_total / groups > 0x7fffffffull?
 	    0x7fffffffull : ctx->rec_total / groups);
@@ -369,7 +379,10 @@ sora_adsb_scan(sora_adsb_ctx *ctx, const void *d_iq, size_t nbytes, int encoding
     r.encoding = encoding;
     r.emit_all = a.emit_all;
     r.groups = groups;
-    r.rec = ctx->d_rec;
+    r.key = a.key;
+    r.tail = a.tail;
+    r.n_tiles = n_tiles;
+    r.tile_pos = sora_scan_tile_pos(encoding, (int) ctx->scan_variant);
     r.rec_count = ctx->d_rec_count;
     r.rec_cap = a.rec_cap;
     r.sq = ctx->d_sq;

@@ -37,7 +37,13 @@ struct sora_scan_args {
     int32_t emit_all;		/* also record dirty squitters */
     int32_t correct;		/* SORA_OPT_CORRECT_SINGLE_BIT */
     int32_t pad_;
-    uint64_t *rec;		/* [groups][rec_cap] unified records */
+    /* candidate records, one per candidate in position order, in two arrays
+     * (6 bytes instead of the 8 of a full record: the scan writes and the
+     * filter reads them all): key = payload[23:0] | kind[25:24] |
+     * region position[21:16] << 26, tail = region position[15:0]; the region
+     * position counts from the first position of the workgroup's tile range */
+    uint32_t *key;		/* [groups][rec_cap] */
+    uint16_t *tail;		/* [groups][rec_cap] */
     uint64_t *sq;		/* [groups][sq_cap] clean squitters */
     uint32_t rec_cap, sq_cap;	/* per-group capacities */
     uint32_t *rec_count;	/* [groups] records produced (may exceed cap) */
@@ -52,7 +58,10 @@ struct sora_resolve_args {
     int32_t encoding;
     int32_t emit_all;
     uint32_t groups;
-    const uint64_t *rec;	/* scan output */
+    const uint32_t *key;	/* scan output, see sora_scan_args */
+    const uint16_t *tail;
+    uint64_t n_tiles;		/* of the scan: region g starts at tile n_tiles * g / groups */
+    uint32_t tile_pos;		/* positions per tile of the scan kernel that ran */
     const uint32_t *rec_count;
     uint32_t rec_cap;
     const uint64_t *sq;
@@ -73,6 +82,10 @@ struct sora_resolve_args {
     uint64_t frames_cap;
 };
 
+#define SORA_REGION_POS_BITS	22	/* a workgroup's tile range spans fewer positions */
+
+/* positions per tile of the scan kernel for this encoding and variant */
+uint32_t sora_scan_tile_pos(int encoding, int variant);
 /* tiles (workgroup passes) a chunk of n_scan positions needs */
 uint64_t sora_scan_tiles(uint64_t n_scan, int encoding, int variant);
 /* LDS bytes / thread count of the scan kernel, for documentation and tests */

@@ -218,7 +218,8 @@ adsb_scan_kernel(sora_scan_args a) {
     const uint64_t tile_begin = a.n_tiles * group / groups;
     const uint64_t tile_end = a.n_tiles * (group + 1) / groups;
 
-    uint64_t *rec_out = a.rec + (uint64_t) group * a.rec_cap;
+    uint32_t *key_out = a.key + (uint64_t) group * a.rec_cap;
+    uint16_t *tail_out = a.tail + (uint64_t) group * a.rec_cap;
     uint64_t *sq_out = a.sq + (uint64_t) group * a.sq_cap;
     uint32_t n_rec = 0;			/* workgroup-uniform */
     if (tid == 0)
@@ -258,6 +259,9 @@ adsb_scan_kernel(sora_scan_args a) {
 
     for (uint64_t tile = tile_begin; tile < tile_end; tile++) {
 	const uint64_t tile_start = tile * kTilePos;
+	/* position of the tile in the workgroup's range (< 2^SORA_REGION_POS_BITS,
+	 * sora_adsb_scan checks) */
+	const uint32_t region_off = (uint32_t) (tile - tile_begin) * (uint32_t) kTilePos;
 	/* the thread index, made opaque once per tile: LDS addresses derived from
 	 * it are then formed inside the loop as one register plus the immediate
 	 * offset field of the ds instructions; hoisted out of the loop they are a
@@ -447,19 +451,18 @@ adsb_scan_kernel(sora_scan_args a) {
 			    payload ^= 1u << (31 - b);
 		    }
 		}
-		/* sora_rec_make(kind, tile_start + q, payload) with the uniform
-		 * part kept scalar: five VALU instructions */
-		const uint32_t rec_lo = (q << 24) | payload;
-		const uint32_t rec_hi = (q >> 8) | ((uint32_t) kind << 28);
-		const uint64_t record = (tile_start << 24) +
-			(((uint64_t) rec_hi << 32) | rec_lo);
+		/* key and tail (sora_scan_args); the full record only for the
+		 * squitter list */
+		const uint32_t rpos = region_off + q;
 		const uint32_t idx = n_rec + i;
-		if (idx < a.rec_cap)
-		    rec_out[idx] = record;
+		if (idx < a.rec_cap) {
+		    key_out[idx] = payload | ((uint32_t) kind << 24) | ((rpos >> 16) << 26);
+		    tail_out[idx] = (uint16_t) rpos;
+		}
 		if (kind == SORA_REC_KIND_SQUITTER || kind == SORA_REC_KIND_CORRECTED) {
 		    const uint32_t k = atomicAdd(&s_sq_total, 1u);
 		    if (k < a.sq_cap)
-			sq_out[k] = record;
+			sq_out[k] = sora_rec_make(kind, tile_start + q, payload);
 		}
 		/* wave-uniform counts: ballots land in SGPRs, off the VALU */
 		st_sq += (uint32_t) __popcll(__ballot(kind == SORA_REC_KIND_SQUITTER));
@@ -541,19 +544,6 @@ next_lane(uint32_t v) {
 #ifndef SORA_DIRECT_WAVES
 #define SORA_DIRECT_WAVES 7
 #endif
-/* cache policy of the record stores and of the sample loads (experiments) */
-#if defined(SORA_PROBE_REC_WINDOW)
-/* timing probe only: every record store lands in a 512 KB window that stays in
- * L2 (wrong results) -- separates the store path from the HBM write traffic */
-#define SORA_REC_STORE(p, v) (a.rec[(((p) - a.rec) & 255) + 256 * (blockIdx.x & 255)] = (v))
-#elif defined(SORA_NT_STORE)
-#define SORA_REC_STORE(p, v) __builtin_nontemporal_store((v), (p))
-#else
-#define SORA_REC_STORE(p, v) (*(p) = (v))
-#endif
-#ifndef SORA_LOAD_AUX
-#define SORA_LOAD_AUX 0
-#endif
 template <int kThreads>
 __global__ void __launch_bounds__(kThreads, SORA_DIRECT_WAVES)
 adsb_scan_direct_kernel(sora_scan_args a) {
@@ -579,7 +569,8 @@ adsb_scan_direct_kernel(sora_scan_args a) {
     const uint64_t tile_begin = a.n_tiles * group / groups;
     const uint64_t tile_end = a.n_tiles * (group + 1) / groups;
 
-    uint64_t *rec_out = a.rec + (uint64_t) group * a.rec_cap;
+    uint32_t *key_out = a.key + (uint64_t) group * a.rec_cap;
+    uint16_t *tail_out = a.tail + (uint64_t) group * a.rec_cap;
     uint64_t *sq_out = a.sq + (uint64_t) group * a.sq_cap;
     uint32_t n_rec = 0;
     uint32_t st_cand = 0, st_sq = 0, st_dirty = 0, st_fixed = 0;
@@ -606,7 +597,7 @@ adsb_scan_direct_kernel(sora_scan_args a) {
 		const_cast<uint8_t *>(a.iq) + start * 2, 0, span, 0x00020000);
 #pragma unroll
 	for (int r = 0; r < 4; r++)
-	    v[r] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, g * 64, r * 16, SORA_LOAD_AUX);
+	    v[r] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, g * 64, r * 16, 0);
     };
 #ifdef SORA_DIRECT_PREFETCH
     u32x4 v[4];
@@ -614,6 +605,9 @@ adsb_scan_direct_kernel(sora_scan_args a) {
 
     for (uint64_t tile = tile_begin; tile < tile_end; tile++) {
 	const uint64_t tile_start = tile * kTilePos;
+	/* position of the tile in the workgroup's range (< 2^SORA_REGION_POS_BITS,
+	 * sora_adsb_scan checks) */
+	const uint32_t region_off = (uint32_t) (tile - tile_begin) * (uint32_t) kTilePos;
 	const uint32_t par = (uint32_t) (tile - tile_begin) & 1;
 	/* lane run of this lane, opaque per tile (see adsb_scan_kernel) */
 	uint32_t g = 63 * wave + lane;
@@ -732,17 +726,16 @@ adsb_scan_direct_kernel(sora_scan_args a) {
 			    payload ^= 1u << (31 - b);
 		    }
 		}
-		const uint32_t rec_lo = (q << 24) | payload;
-		const uint32_t rec_hi = (q >> 8) | (kind << 28);
-		const uint64_t record = (tile_start << 24) +
-			(((uint64_t) rec_hi << 32) | rec_lo);
+		const uint32_t rpos = region_off + q;
 		const uint32_t idx = n_rec + i;
-		if (idx < a.rec_cap)
-		    SORA_REC_STORE(&rec_out[idx], record);
+		if (idx < a.rec_cap) {
+		    key_out[idx] = payload | (kind << 24) | ((rpos >> 16) << 26);
+		    tail_out[idx] = (uint16_t) rpos;
+		}
 		if (kind == SORA_REC_KIND_SQUITTER || kind == SORA_REC_KIND_CORRECTED) {
 		    const uint32_t k = atomicAdd(&s_sq_total, 1u);
 		    if (k < a.sq_cap)
-			sq_out[k] = record;
+			sq_out[k] = sora_rec_make(kind, tile_start + q, payload);
 		}
 		st_sq += (uint32_t) __popcll(__ballot(kind == SORA_REC_KIND_SQUITTER));
 		st_dirty += (uint32_t) __popcll(__ballot(kind == SORA_REC_KIND_DIRTY));
@@ -1006,7 +999,11 @@ filter_kernel(sora_resolve_args a) {
 	return;
     const uint32_t group = region / a.filter_parts;
     const uint32_t part = region % a.filter_parts;
-    const uint64_t *rec = a.rec + (uint64_t) group * a.rec_cap;
+    const uint32_t *key = a.key + (uint64_t) group * a.rec_cap;
+    const uint16_t *tail = a.tail + (uint64_t) group * a.rec_cap;
+    /* first position of the scan region: its first tile (as the scan kernel
+     * computes it) times the tile width */
+    const uint64_t region_first = (a.n_tiles * group / a.groups) * a.tile_pos;
     uint64_t *acc = a.acc + (uint64_t) region * a.acc_cap;
     uint32_t n = a.rec_count[group];
     uint32_t n_acc = 0;
@@ -1017,32 +1014,39 @@ filter_kernel(sora_resolve_args a) {
     const uint32_t end = (uint32_t) ((uint64_t) n * (part + 1) / a.filter_parts);
 
     for (uint32_t base = begin; base < end; base += 64 * kFilterUnroll) {
+	uint32_t k[kFilterUnroll], t[kFilterUnroll];
 	uint64_t r[kFilterUnroll];
 	bool keep[kFilterUnroll];
 #pragma unroll
 	for (int u = 0; u < kFilterUnroll; u++) {
 	    const uint32_t i = base + u * 64 + lane;
-	    r[u] = i < end? rec[i] : ~0ull;	/* kind 15: dropped below */
+	    k[u] = i < end? key[i] : 0xffffffffu;
+	    t[u] = i < end? tail[i] : 0u;
 	}
 #pragma unroll
 	for (int u = 0; u < kFilterUnroll; u++) {
-	    const uint32_t kind = sora_rec_kind(r[u]);
+	    const uint32_t i = base + u * 64 + lane;
+	    const uint32_t kind = (k[u] >> 24) & 3u;
+	    const uint32_t addr = k[u] & 0xffffffu;
+	    const uint64_t pos = region_first + (((k[u] >> 26) << 16) | t[u]);
 	    keep[u] = false;
-	    if (kind == SORA_REC_KIND_SQUITTER || kind == SORA_REC_KIND_CORRECTED) {
+	    r[u] = sora_rec_make(kind, pos, addr);
+	    if (i >= end) {
+		/* past the part: dropped */
+	    } else if (kind == SORA_REC_KIND_SQUITTER || kind == SORA_REC_KIND_CORRECTED) {
 		keep[u] = true;
 		r[u] |= SORA_REC_ACCEPTED << 60;
 	    } else if (kind == SORA_REC_KIND_REPLY) {
-		const uint32_t addr = sora_rec_addr(r[u]);
 		const uint32_t f = addr & ((1u << SORA_KNOWN_FOLD_BITS) - 1);
 		bool known = (s_fold[f >> 5] >> (addr & 31)) & 1;
 		if (known)
 		    known = (a.known_bits[addr >> 5] >> (addr & 31)) & 1;
 		if (known)
-		    known = a.first_seen[addr] < a.base_position + sora_rec_pos(r[u]);
+		    known = a.first_seen[addr] < a.base_position + pos;
 		if (known)
 		    r[u] |= SORA_REC_ACCEPTED << 60;
 		keep[u] = known || a.emit_all;
-	    } else if (kind == SORA_REC_KIND_DIRTY) {
+	    } else {				/* SORA_REC_KIND_DIRTY */
 		keep[u] = a.emit_all != 0;
 	    }
 	}
@@ -1394,13 +1398,18 @@ grid_for(uint64_t n, uint32_t block) {
 
 /* ---------------------------------------------------------- launchers -- */
 
+uint32_t
+sora_scan_tile_pos(int encoding, int variant) {
+    if (encoding != SORA_ENC_SC16 && variant == 1)
+	return direct_geom<256>::tile_pos;
+    if (encoding != SORA_ENC_SC16 && variant == 2)
+	return direct_geom<512>::tile_pos;
+    return encoding == SORA_ENC_SC16? SORA16_TILE_POS : SORA_TILE_POS;
+}
+
 uint64_t
 sora_scan_tiles(uint64_t n_scan, int encoding, int variant) {
-    uint64_t pos = encoding == SORA_ENC_SC16? SORA16_TILE_POS : SORA_TILE_POS;
-    if (encoding != SORA_ENC_SC16 && variant == 1)
-	pos = direct_geom<256>::tile_pos;
-    if (encoding != SORA_ENC_SC16 && variant == 2)
-	pos = direct_geom<512>::tile_pos;
+    const uint64_t pos = sora_scan_tile_pos(encoding, variant);
     return (n_scan + pos - 1) / pos;
 }
 
