@@ -370,6 +370,12 @@ sora_adsb_scan(sora_adsb_ctx *ctx, const void *d_iq, size_t nbytes, int encoding
     a.rec_count = ctx->d_rec_count;
     a.sq_count = ctx->d_sq_count;
     a.stats = ctx->d_stats;
+    const bool merges = sora_scan_merges(encoding, (int) ctx->scan_variant) != 0;
+    if (merges) {
+	a.first_seen = ctx->d_first_seen;
+	a.known_bits = ctx->d_known_bits;
+	a.base_position = base_position;
+    }
 
     sora_resolve_args &r = ctx->res;
     memset(&r, 0, sizeof r);
@@ -404,7 +410,8 @@ sora_adsb_scan(sora_adsb_ctx *ctx, const void *d_iq, size_t nbytes, int encoding
     ctx->groups = groups;
     ctx->scanned = false;
     ctx->resolved = false;
-    ctx->merged = ctx->exported = false;
+    ctx->merged = merges;		/* else first_seen_kernel, before the first use */
+    ctx->exported = false;
 
     HIP_TRY(ctx, hipEventRecord(ctx->ev_scan_begin, ctx->stream));
     HIP_TRY(ctx, sora_launch_scan(&a, groups, (int) ctx->scan_variant, ctx->stream));
