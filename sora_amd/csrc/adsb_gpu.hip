@@ -283,7 +283,9 @@ sora_adsb_create(sora_adsb_ctx **out, int device, const sora_adsb_config *cfg) {
 
     const uint32_t g = ctx->max_groups;
     const uint32_t nr = ctx->max_regions;
-    if (dev_alloc(&ctx->d_rec, ctx->rec_total) != hipSuccess ||
+    /* 8 bytes per record slot for 6 used: room for the alignment of the tails
+     * and for the filter's 16-byte loads past a short region */
+    if (dev_alloc(&ctx->d_rec, ctx->rec_total + 8) != hipSuccess ||
 	    dev_alloc(&ctx->d_acc_flat, ctx->frames_cap) != hipSuccess ||
 	    dev_alloc(&ctx->d_known_bits, SORA_KNOWN_WORDS) != hipSuccess ||
 	    dev_alloc(&ctx->d_sq, ctx->sq_total) != hipSuccess ||
@@ -361,10 +363,12 @@ sora_adsb_scan(sora_adsb_ctx *ctx, const void *d_iq, size_t nbytes, int encoding
     /* the record buffer holds the 4-byte keys, then the 2-byte tails */
     a.key = reinterpret_cast<uint32_t *>(ctx->d_rec);
     a.tail = reinterpret_cast<uint16_t *>(reinterpret_cast<uint32_t *>(ctx->d_rec) +
-	    ctx->rec_total);
+	    ((ctx->rec_total + 3) & ~3ull));	/* 16-byte aligned */
     a.sq = ctx->d_sq;
     a.rec_cap = (uint32_t) (ctx->rec_total / groups > 0x7fffffffull?
 	    0x7fffffffull : ctx->rec_total / groups);
+    if (a.rec_cap >= 8)
+	a.rec_cap &= ~7u;	/* the filter loads eight records at a time, aligned */
     a.sq_cap = (uint32_t) (ctx->sq_total / groups > 0x7fffffffull?
 	    0x7fffffffull : ctx->sq_total / groups);
     a.rec_count = ctx->d_rec_count;

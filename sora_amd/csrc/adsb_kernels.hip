@@ -989,8 +989,8 @@ export_first_kernel(sora_resolve_args a, uint64_t *dst, uint64_t dst_cap,
  * position P with address A is accepted iff first_seen[A] < P.  Each wave
  * takes a contiguous part of one scan region (a.filter_parts parts per region)
  * and compacts it, in order, into an accepted region of its own
- * (region = filter_parts * group + part): no barriers, eight independent
- * record loads in flight per lane.
+ * (region = filter_parts * group + part): no barriers, eight records per lane
+ * and iteration.
  */
 constexpr int kFilterWaves = kSmall / 64;
 constexpr int kFilterUnroll = 8;
@@ -1029,31 +1029,48 @@ filter_kernel(sora_resolve_args a) {
 
     if (n > a.rec_cap)
 	n = a.rec_cap;
-    const uint32_t begin = (uint32_t) ((uint64_t) n * part / a.filter_parts);
-    const uint32_t end = (uint32_t) ((uint64_t) n * (part + 1) / a.filter_parts);
+    /* parts begin at multiples of eight records: with rec_cap a multiple of
+     * eight (sora_adsb_scan) a lane's eight keys are 32 aligned bytes and its
+     * eight tails 16 */
+    const uint32_t begin = (uint32_t) ((uint64_t) n * part / a.filter_parts) & ~7u;
+    const uint32_t end = part + 1 == a.filter_parts? n :
+	    (uint32_t) ((uint64_t) n * (part + 1) / a.filter_parts) & ~7u;
 
+    /* a lane takes EIGHT CONSECUTIVE records: two 16-byte loads of keys and one
+     * of tails (three load instructions per 512 records where one record per
+     * lane and load took sixteen); the kept ones go out in lane order behind a
+     * wave prefix sum of the lanes' counts */
     for (uint32_t base = begin; base < end; base += 64 * kFilterUnroll) {
+	const uint32_t i0 = base + lane * kFilterUnroll;
 	uint32_t k[kFilterUnroll], t[kFilterUnroll];
 	uint64_t r[kFilterUnroll];
-	bool keep[kFilterUnroll];
+	uint32_t keep = 0;
+	{
+	    u32x4 ka = {0, 0, 0, 0}, kb = {0, 0, 0, 0}, tt = {0, 0, 0, 0};
+	    if (i0 < end) {		/* the loads may pass `end`, never the region */
+		ka = *reinterpret_cast<const u32x4 *>(key + i0);
+		kb = *reinterpret_cast<const u32x4 *>(key + i0 + 4);
+		tt = *reinterpret_cast<const u32x4 *>(tail + i0);
+	    }
 #pragma unroll
-	for (int u = 0; u < kFilterUnroll; u++) {
-	    const uint32_t i = base + u * 64 + lane;
-	    k[u] = i < end? key[i] : 0xffffffffu;
-	    t[u] = i < end? tail[i] : 0u;
+	    for (int u = 0; u < 4; u++) {
+		k[u] = ka[u];
+		k[4 + u] = kb[u];
+		t[2 * u] = tt[u] & 0xffffu;
+		t[2 * u + 1] = tt[u] >> 16;
+	    }
 	}
 #pragma unroll
 	for (int u = 0; u < kFilterUnroll; u++) {
-	    const uint32_t i = base + u * 64 + lane;
 	    const uint32_t kind = (k[u] >> 24) & 3u;
 	    const uint32_t addr = k[u] & 0xffffffu;
 	    const uint64_t pos = region_first + (((k[u] >> 26) << 16) | t[u]);
-	    keep[u] = false;
+	    bool kept = false;
 	    r[u] = sora_rec_make(kind, pos, addr);
-	    if (i >= end) {
+	    if (i0 + u >= end) {
 		/* past the part: dropped */
 	    } else if (kind == SORA_REC_KIND_SQUITTER || kind == SORA_REC_KIND_CORRECTED) {
-		keep[u] = true;
+		kept = true;
 		r[u] |= SORA_REC_ACCEPTED << 60;
 	    } else if (kind == SORA_REC_KIND_REPLY) {
 		const uint32_t f = addr & ((1u << SORA_KNOWN_FOLD_BITS) - 1);
@@ -1064,22 +1081,24 @@ filter_kernel(sora_resolve_args a) {
 		    known = a.first_seen[addr] < a.base_position + pos;
 		if (known)
 		    r[u] |= SORA_REC_ACCEPTED << 60;
-		keep[u] = known || a.emit_all;
+		kept = known || a.emit_all;
 	    } else {				/* SORA_REC_KIND_DIRTY */
-		keep[u] = a.emit_all != 0;
+		kept = a.emit_all != 0;
 	    }
+	    keep |= (uint32_t) kept << u;
 	}
+	if (__ballot(keep != 0) != 0) {		/* most batches of noise keep nothing */
+	    const uint32_t cnt = __popc(keep);
+	    const uint32_t incl = wave_inclusive_scan(cnt);
+	    uint32_t idx = n_acc + incl - cnt;
 #pragma unroll
-	for (int u = 0; u < kFilterUnroll; u++) {
-	    const unsigned long long m = __ballot(keep[u]);
-	    if (m == 0)
-		continue;
-	    if (keep[u]) {
-		const uint32_t idx = n_acc + rank_in_mask(m);
-		if (idx < a.acc_cap)
-		    acc[idx] = r[u];
-	    }
-	    n_acc += (uint32_t) __popcll(m);
+	    for (int u = 0; u < kFilterUnroll; u++)
+		if (keep & (1u << u)) {
+		    if (idx < a.acc_cap)
+			acc[idx] = r[u];
+		    idx++;
+		}
+	    n_acc += (uint32_t) __builtin_amdgcn_readlane((int) incl, 63);
 	}
     }
     if (lane == 0)
