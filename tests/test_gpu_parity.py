@@ -662,3 +662,30 @@ def test_scan_variants_noise_dense_hits_and_correction(monkeypatch, variant, enc
     got, counts = gpu_frames(raw, correct_single_bit=True)
     assert_same_frames(got, want)
     assert counts["corrected"] == n_fixed
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_long_scan_regions(monkeypatch, variant):
+    """A candidate record carries its position relative to the first tile of its
+    workgroup's range in 22 bits (6 in the key, 16 in the tail).  One workgroup
+    for the whole capture makes every bit of that matter; a range too long for
+    22 bits is refused, not wrapped."""
+    monkeypatch.setenv("SORA_ADSB_SCAN_VARIANT", str(variant))
+    monkeypatch.setenv("SORA_ADSB_SCAN_MIN_TILES", "1000000")
+    p = synth.default_params(2, n_samples=3000000, mean_gap=3000, reply_permille=200,
+                             unknown_permille=300, n_icao=7, seed=31)
+    raw = synth.fill_host(p.n_samples, p.encoding, p.seed, synth.make_frames(p)).tobytes()
+    want = ob.scan(raw)
+    got, counts = gpu_frames(raw)
+    assert_same_frames(got, want)
+    assert counts["candidates"] == len(want)
+    assert got[-1]["position"] > 2900000
+    acc, _ = gpu_frames(raw, emit=EMIT_ACCEPTED)
+    assert_same_frames(acc, [c for c in want if c["accepted"]])
+    # 2^22 positions and more in one range
+    n = (1 << 22) + 20000
+    buf = DeviceBuffer.from_host(bytes(2 * n + 16))
+    with AdsbContext(n) as ctx:
+        with pytest.raises(sora_amd.SoraError) as e:
+            ctx.submit_device(buf, 2 * n, ENC_UC8)
+        assert "too long" in str(e.value)
