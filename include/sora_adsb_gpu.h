@@ -142,7 +142,11 @@ int sora_adsb_reset(sora_adsb_ctx *ctx);
  * p + 240 <= n_samples (plane-iq.c:148-166): a middle shard
  * passes its owned count and carries 239 halo samples behind it, the last
  * shard passes n_owned = n_samples.  base_position is the global index of
- * the chunk's first sample.
+ * the chunk's first sample.  SORA_ERR_INVALID also when a workgroup's range of
+ * tiles would span 2^22 positions or more (a candidate record carries its
+ * position relative to that range in 22 bits): chunks beyond about 10^11
+ * samples, or less with SORA_ADSB_SCAN_ROUNDS / SORA_ADSB_SCAN_MIN_TILES set
+ * to few, long ranges.
  */
 int sora_adsb_scan(sora_adsb_ctx *ctx, const void *d_iq, size_t nbytes,
 	int encoding, uint64_t base_position, uint64_t n_owned);
