@@ -49,9 +49,9 @@ struct sora_scan_args {
     uint32_t *rec_count;	/* [groups] records produced (may exceed cap) */
     uint32_t *sq_count;		/* [groups] */
     uint64_t *stats;		/* [groups][SORA_STAT_WORDS] */
-    /* the register-resident 8-bit kernels merge a workgroup's clean squitters
-     * into the first-seen table as the workgroup ends (first_seen_kernel's
-     * work, hidden behind the other workgroups of the CU); NULL: not merged */
+    /* the scan kernels merge a workgroup's clean squitters into the first-seen
+     * table as the workgroup ends (first_seen_kernel's work, hidden behind
+     * the other workgroups of the CU); NULL: not merged */
     uint64_t *first_seen;
     uint32_t *known_bits;
     uint64_t base_position;

@@ -170,6 +170,32 @@ lds_barrier() {
 #define STAMP_WAIT_LDS()
 #endif
 
+__device__ __forceinline__ void note_known(uint64_t *first_seen, uint32_t *known_bits,
+	uint32_t addr, uint64_t position);
+
+/*
+ * first_seen_kernel's work for one workgroup's squitter list (about sixty
+ * entries of the 1-hour capture), done by the scan kernel as the workgroup
+ * ends: four dependent round trips that the other workgroups of the CU cover,
+ * instead of a kernel of its own that does nothing else (0.08 ms per capture).
+ * Call behind a barrier at which every wave has waited for its list stores;
+ * the list is read past the L1.
+ */
+__device__ __forceinline__ void
+merge_squitter_list(const sora_scan_args &a, const uint64_t *sq_out, uint32_t n,
+	uint32_t tid, uint32_t threads) {
+    if (a.first_seen == nullptr)
+	return;
+    if (n > a.sq_cap)
+	n = a.sq_cap;
+    for (uint32_t i = tid; i < n; i += threads) {
+	const uint64_t r = __hip_atomic_load(&sq_out[i], __ATOMIC_RELAXED,
+		__HIP_MEMORY_SCOPE_AGENT);
+	note_known(a.first_seen, a.known_bits, sora_rec_addr(r),
+		a.base_position + sora_rec_pos(r));
+    }
+}
+
 template <bool kWide>
 __global__ void __launch_bounds__(tile_geom<kWide>::threads, tile_geom<kWide>::waves_per_simd)
 adsb_scan_kernel(sora_scan_args a) {
@@ -514,6 +540,7 @@ adsb_scan_kernel(sora_scan_args a) {
 #endif
 	}
     }
+    merge_squitter_list(a, sq_out, s_sq_total, tid, kThreads);
 }
 
 /*
@@ -527,9 +554,6 @@ adsb_scan_kernel(sora_scan_args a) {
  * by tile parity, the hit prefix and the queue: two barriers per tile instead
  * of four, 22 KB of LDS instead of 53.
  */
-__device__ __forceinline__ void note_known(uint64_t *first_seen, uint32_t *known_bits,
-	uint32_t addr, uint64_t position);
-
 template <int kThreads> struct direct_geom {
     static constexpr int waves = kThreads / 64;
     static constexpr int lanes = 63 * waves;		/* lane runs computed */
@@ -779,22 +803,7 @@ adsb_scan_direct_kernel(sora_scan_args a) {
 	    st[SORA_STAT_CORRECTED] = t3;
 	}
     }
-    /* first_seen_kernel's work for this workgroup's squitter list (about sixty
-     * entries of the 1-hour capture): four dependent round trips that the other
-     * workgroups of the CU cover, instead of a kernel of its own that does
-     * nothing else (0.08 ms per capture).  Every wave has waited for its list
-     * stores at the barrier above; the list is read past the L1. */
-    if (a.first_seen != nullptr) {
-	uint32_t n = s_sq_total;
-	if (n > a.sq_cap)
-	    n = a.sq_cap;
-	for (uint32_t i = tid; i < n; i += kThreads) {
-	    const uint64_t r = __hip_atomic_load(&sq_out[i], __ATOMIC_RELAXED,
-		    __HIP_MEMORY_SCOPE_AGENT);
-	    note_known(a.first_seen, a.known_bits, sora_rec_addr(r),
-		    a.base_position + sora_rec_pos(r));
-	}
-    }
+    merge_squitter_list(a, sq_out, s_sq_total, tid, kThreads);
 }
 
 /* ------------------------------------------------------- small kernels -- */
@@ -1438,7 +1447,9 @@ grid_for(uint64_t n, uint32_t block) {
 
 int
 sora_scan_merges(int encoding, int variant) {
-    return encoding != SORA_ENC_SC16 && (variant == 1 || variant == 2);
+    (void) encoding;
+    (void) variant;
+    return 1;		/* every scan kernel does */
 }
 
 uint32_t
