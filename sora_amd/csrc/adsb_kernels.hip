@@ -1374,6 +1374,12 @@ finalize_four(const sora_resolve_args &a, uint64_t f, bool valid, uint64_t r,
     }
 }
 
+/* blocks per CU of the finalize kernel: 82 VGPRs hold 5 at a time; measured
+ * resolve 0.518 ms with 8, 0.507 with 5, 0.54 with 6, 0.505 with 12, 0.498 with
+ * 24 (short-lived blocks even out the tail) */
+#ifndef SORA_FINALIZE_BLOCKS
+#define SORA_FINALIZE_BLOCKS 24
+#endif
 constexpr int kFinalizeDepth = 2;	/* rounds (of four frames) whose sample fetches are in flight */
 
 template <bool kWide>
@@ -1607,14 +1613,14 @@ sora_launch_finalize(const sora_resolve_args *a, uint32_t cus, hipStream_t strea
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)
 	return e;
-    /* 8 blocks of 4 waves per CU: every wave slot busy hiding the two
-     * dependent fetches (record, then samples) of a frame */
+    /* SORA_FINALIZE_BLOCKS blocks of 4 waves per CU: every wave slot busy
+     * hiding the two dependent fetches (record, then samples) of a frame */
     (void) hipGetLastError();
     if (a->encoding == SORA_ENC_SC16)
-	hipLaunchKernelGGL(finalize_kernel<true>, dim3(cus * 8), dim3(kSmall), 0,
+	hipLaunchKernelGGL(finalize_kernel<true>, dim3(cus * SORA_FINALIZE_BLOCKS), dim3(kSmall), 0,
 		stream, *a);
     else
-	hipLaunchKernelGGL(finalize_kernel<false>, dim3(cus * 8), dim3(kSmall), 0,
+	hipLaunchKernelGGL(finalize_kernel<false>, dim3(cus * SORA_FINALIZE_BLOCKS), dim3(kSmall), 0,
 		stream, *a);
     return hipGetLastError();
 }
