@@ -41,7 +41,8 @@ extern "C" {
 #define SORA_ERR_INVALID	(-1)	/* bad argument */
 #define SORA_ERR_NO_DEVICE	(-2)	/* no usable gfx950 device */
 #define SORA_ERR_HIP		(-3)	/* a HIP call failed: sora_adsb_last_error() */
-#define SORA_ERR_OVERFLOW	(-4)	/* a device list was too small; see sora_adsb_get_counts */
+#define SORA_ERR_OVERFLOW	(-4)	/* a device list was too small and could not be
+					 * grown; see SORA_OPT_FIXED_LISTS */
 #define SORA_ERR_NOMEM		(-5)
 #define SORA_ERR_ALIGN		(-6)	/* device pointer not 16-byte aligned */
 #define SORA_ERR_STATE		(-7)	/* call out of order */
@@ -77,6 +78,23 @@ extern "C" {
  * known from its position on like any squitter's.
  */
 #define SORA_OPT_CORRECT_SINGLE_BIT	0x01
+/*
+ * The device lists (candidate records, clean squitters, accepted frames) are
+ * sized by sora_adsb_config and shared out evenly over the scan's workgroup
+ * regions, so a burst of candidates can overflow one region while the lists are
+ * nearly empty overall.  The reference never drops a candidate
+ * (plane-iq.c:141-194), and by default neither does this library: the kernels
+ * count what they could not store, and sora_adsb_collect / _get_counts /
+ * _stream_next then allocate lists of the sizes that were needed and run the
+ * chunk again before they return (the IQ buffer of the scan must still be in
+ * place, as it must be for the resolve anyway).  With SORA_OPT_FIXED_LISTS the
+ * lists never change and an overflow is reported as SORA_ERR_OVERFLOW (for
+ * callers that must not allocate after create, and for tests of that report).
+ * One case is reported even without it: a squitter list that overflowed AFTER
+ * its export went to other shards (sora_adsb_export_block, _copy_squitters) --
+ * they have merged a truncated list, a local re-run cannot repair that.
+ */
+#define SORA_OPT_FIXED_LISTS		0x02
 
 /* 48 bytes, what the demodulator + validator know about one frame */
 struct sora_adsb_frame {
@@ -99,8 +117,10 @@ struct sora_adsb_frame {
 
 struct sora_adsb_config {
     uint64_t max_chunk_samples;	/* largest chunk a scan will be given */
-    uint64_t max_candidates;	/* device list sizes; 0 = max_chunk_samples/16 */
-    uint64_t max_squitters;	/* 0 = max_chunk_samples/256 + 4096 */
+    uint64_t max_candidates;	/* initial device list sizes (they grow on
+				 * overflow, see SORA_OPT_FIXED_LISTS);
+				 * 0 = max_chunk_samples/16 + 65536 */
+    uint64_t max_squitters;	/* 0 = max_chunk_samples/256 + 65536 */
     uint64_t max_frames;	/* 0 = max_squitters (EMIT_ACCEPTED) or
 				 * max_candidates (EMIT_CANDIDATES) */
     int32_t emit_mode;		/* SORA_EMIT_* */
@@ -142,7 +162,10 @@ int sora_adsb_reset(sora_adsb_ctx *ctx);
  * p + 240 <= n_samples (plane-iq.c:148-166): a middle shard
  * passes its owned count and carries 239 halo samples behind it, the last
  * shard passes n_owned = n_samples.  base_position is the global index of
- * the chunk's first sample.  SORA_ERR_INVALID also when a workgroup's range of
+ * the chunk's first sample.  An odd 8-bit sample count reads the last dword of
+ * the buffer whole (two bytes past nbytes, inside the 16-byte alignment slack
+ * every device allocation has); those bytes only reach positions the
+ * p + 240 <= n_samples rule drops.  SORA_ERR_INVALID also when a workgroup's range of
  * tiles would span 2^22 positions or more (a candidate record carries its
  * position relative to that range in 22 bits): chunks beyond about 10^11
  * samples, or less with SORA_ADSB_SCAN_ROUNDS / SORA_ADSB_SCAN_MIN_TILES set
@@ -226,8 +249,8 @@ int sora_adsb_stream_end(sora_adsb_ctx *ctx);
  * Waits for the stream, then copies the frames of the last resolve, in
  * increasing position, to host memory (sora_adsb_collect) or to a device
  * buffer (sora_adsb_collect_device).  *n is the number available; at most
- * cap are written.  Returns SORA_ERR_OVERFLOW if a device list overflowed
- * during the scan (sora_adsb_get_counts then tells the sizes that were needed).
+ * cap are written.  A device list that overflowed is grown and the chunk run
+ * again first (SORA_OPT_FIXED_LISTS: SORA_ERR_OVERFLOW instead).
  */
 int sora_adsb_collect(sora_adsb_ctx *ctx, struct sora_adsb_frame *out,
 	size_t cap, size_t *n);
@@ -235,6 +258,8 @@ int sora_adsb_collect_device(sora_adsb_ctx *ctx, void *d_out, size_t cap,
 	size_t *n);
 
 int sora_adsb_get_counts(sora_adsb_ctx *ctx, struct sora_adsb_counts *out); /* syncs */
+/* How often this context has re-run a chunk with larger lists so far. */
+int sora_adsb_list_regrows(const sora_adsb_ctx *ctx);
 int sora_adsb_synchronize(sora_adsb_ctx *ctx);
 
 /* Duration of the last scan kernel alone, HIP events on the context's

@@ -23,6 +23,7 @@ ENCODING_NAMES = {"uc8": ENC_UC8, "sc8": ENC_SC8, "sc16": ENC_SC16}
 EMIT_ACCEPTED, EMIT_CANDIDATES = 0, 1
 FRAME_LONG, FRAME_SQUITTER, FRAME_ACCEPTED, FRAME_CORRECTED = 1, 2, 4, 8
 OPT_CORRECT_SINGLE_BIT = 1
+OPT_FIXED_LISTS = 2
 WINDOW, HALO = 240, 239
 
 
@@ -146,6 +147,7 @@ _SIGNATURES = {
     "sora_adsb_collect_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t,
                                            C.POINTER(C.c_size_t)]),
     "sora_adsb_get_counts": (C.c_int, [C.c_void_p, C.POINTER(Counts)]),
+    "sora_adsb_list_regrows": (C.c_int, [C.c_void_p]),
     "sora_adsb_synchronize": (C.c_int, [C.c_void_p]),
     "sora_adsb_last_scan_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "sora_adsb_scan_kernel_name": (C.c_char_p, [C.c_void_p, C.c_int]),

@@ -63,9 +63,11 @@ class AdsbContext:
 
     def __init__(self, max_chunk_samples, device=0, emit_mode=EMIT_ACCEPTED,
                  max_candidates=0, max_squitters=0, max_frames=0, stream=None,
-                 correct_single_bit=False):
+                 correct_single_bit=False, fixed_lists=False):
         self.device = device
         options = _lib.OPT_CORRECT_SINGLE_BIT if correct_single_bit else 0
+        if fixed_lists:
+            options |= _lib.OPT_FIXED_LISTS
         cfg = Config(int(max_chunk_samples), int(max_candidates), int(max_squitters),
                      int(max_frames), int(emit_mode), options, stream)
         h = C.c_void_p()
@@ -220,6 +222,10 @@ class AdsbContext:
         d = {k: getattr(c, k) for k, _ in Counts._fields_}
         d["overflow"] = rc == _lib.ERR_OVERFLOW
         return d
+
+    def list_regrows(self):
+        """Chunks this context ran again with larger lists after an overflow."""
+        return lib().sora_adsb_list_regrows(self._h)
 
     def synchronize(self):
         check(lib().sora_adsb_synchronize(self._h), self._h)

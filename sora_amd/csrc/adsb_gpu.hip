@@ -49,6 +49,17 @@ struct sora_adsb_ctx {
     bool scanned, resolved;
     bool merged;		/* its squitters are in first_seen */
     bool exported;		/* d_export holds its first-seen records */
+    bool exchanged;		/* its squitter export has left the context (another
+				 * shard may have merged it): a squitter-list overflow
+				 * can then no longer be repaired by a local re-run */
+    /* arguments of the last scan: a list overflow re-runs it with larger lists */
+    struct {
+	const void *d_iq;
+	size_t nbytes;
+	int encoding;
+	uint64_t base_position, n_owned;
+    } last;
+    uint32_t regrows;		/* re-runs so far (sora_adsb_regrow_count) */
     uint64_t *d_export;		/* one record per address first seen in this scan */
     uint64_t export_cap;
     sora_scan_args scan;
@@ -64,6 +75,7 @@ struct sora_adsb_ctx {
 	void *user;
 	uint8_t *h_in[2], *d_in[2];
 	sora_adsb_frame *h_out[2];
+	uint64_t out_cap[2];	/* frames h_out[slot] holds */
 	hipStream_t copy;
 	hipEvent_t ev_in[2];	/* block is on the device */
 	hipEvent_t ev_free[2];	/* the kernels are done with d_in[slot] */
@@ -129,6 +141,67 @@ dev_alloc(T **p, uint64_t n) {
     return hipMalloc(reinterpret_cast<void **>(p), (n > 0? n : 1) * sizeof(T));
 }
 
+/*
+ * The lists whose sizes depend on the traffic: candidate records (8 bytes per
+ * slot for the 6 used: room for the alignment of the tails and for the
+ * filter's 16-byte loads past a short region), clean squitters, accepted
+ * records (per region and flat) and frames.  Allocated by sora_adsb_create()
+ * from the configuration and again, larger, when a scan overflowed them.
+ */
+void
+free_lists(sora_adsb_ctx *ctx) {
+    (void) hipFree(ctx->d_rec);
+    (void) hipFree(ctx->d_sq);
+    (void) hipFree(ctx->d_acc);
+    (void) hipFree(ctx->d_acc_flat);
+    (void) hipFree(ctx->d_frames);
+    ctx->d_rec = ctx->d_sq = ctx->d_acc = ctx->d_acc_flat = nullptr;
+    ctx->d_frames = nullptr;
+}
+
+/* shares the lists out over the workgroup regions of the scan at hand
+ * (ctx->groups, ctx->res.regions): pointers and per-region capacities */
+void
+bind_lists(sora_adsb_ctx *ctx) {
+    sora_scan_args &a = ctx->scan;
+    sora_resolve_args &r = ctx->res;
+    const uint32_t groups = ctx->groups;
+    const auto share = [](uint64_t total, uint32_t parts) {
+	const uint64_t each = total / (parts > 0? parts : 1);
+	return (uint32_t) (each > 0x7fffffffull? 0x7fffffffull : each);
+    };
+
+    /* the record buffer holds the 4-byte keys, then the 2-byte tails */
+    a.key = reinterpret_cast<uint32_t *>(ctx->d_rec);
+    a.tail = reinterpret_cast<uint16_t *>(reinterpret_cast<uint32_t *>(ctx->d_rec) +
+	    ctx->rec_total);			/* rec_total is a multiple of 8 */
+    a.sq = ctx->d_sq;
+    a.rec_cap = share(ctx->rec_total, groups) & ~7u;	/* >= 8: sora_adsb_scan */
+    a.sq_cap = share(ctx->sq_total, groups);
+    r.key = a.key;
+    r.tail = a.tail;
+    r.rec_cap = a.rec_cap;
+    r.sq = ctx->d_sq;
+    r.sq_cap = a.sq_cap;
+    r.acc = ctx->d_acc;
+    r.acc_cap = share(ctx->acc_total, r.regions);
+    r.acc_flat = ctx->d_acc_flat;
+    r.frames = ctx->d_frames;
+    r.frames_cap = ctx->frames_cap;
+}
+
+hipError_t
+alloc_lists(sora_adsb_ctx *ctx) {
+    hipError_t e;
+    if ((e = dev_alloc(&ctx->d_rec, ctx->rec_total + 8)) != hipSuccess ||
+	    (e = dev_alloc(&ctx->d_sq, ctx->sq_total)) != hipSuccess ||
+	    (e = dev_alloc(&ctx->d_acc, ctx->acc_total)) != hipSuccess ||
+	    (e = dev_alloc(&ctx->d_acc_flat, ctx->frames_cap)) != hipSuccess ||
+	    (e = dev_alloc(&ctx->d_frames, ctx->frames_cap)) != hipSuccess)
+	return e;
+    return hipSuccess;
+}
+
 } /* namespace */
 
 extern "C" const char *
@@ -175,10 +248,7 @@ sora_adsb_destroy(sora_adsb_ctx *ctx) {
 	(void) hipStreamSynchronize(ctx->st.copy);
 	stream_release(ctx);
     }
-    (void) hipFree(ctx->d_rec);
-    (void) hipFree(ctx->d_sq);
-    (void) hipFree(ctx->d_acc);
-    (void) hipFree(ctx->d_acc_flat);
+    free_lists(ctx);
     (void) hipFree(ctx->d_known_bits);
     (void) hipFree(ctx->d_first_seen);
     (void) hipFree(ctx->d_stats);
@@ -188,7 +258,6 @@ sora_adsb_destroy(sora_adsb_ctx *ctx) {
     (void) hipFree(ctx->d_rec_count);
     (void) hipFree(ctx->d_sq_count);
     (void) hipFree(ctx->d_acc_count);
-    (void) hipFree(ctx->d_frames);
     (void) hipFree(ctx->d_stage);
     if (ctx->h_counts != nullptr)
 	(void) hipHostFree(ctx->h_counts);
@@ -274,6 +343,7 @@ sora_adsb_create(sora_adsb_ctx **out, int device, const sora_adsb_config *cfg) {
 
     const uint64_t n = cfg->max_chunk_samples;
     ctx->rec_total = cfg->max_candidates != 0? cfg->max_candidates : n / 16 + 65536;
+    ctx->rec_total = (ctx->rec_total + 7) & ~7ull;	/* regions of whole 8-record groups */
     ctx->sq_total = cfg->max_squitters != 0? cfg->max_squitters : n / 256 + 65536;
     ctx->acc_total = cfg->max_frames != 0? cfg->max_frames :
 	    cfg->emit_mode == SORA_EMIT_CANDIDATES? ctx->rec_total : ctx->sq_total;
@@ -283,14 +353,8 @@ sora_adsb_create(sora_adsb_ctx **out, int device, const sora_adsb_config *cfg) {
 
     const uint32_t g = ctx->max_groups;
     const uint32_t nr = ctx->max_regions;
-    /* 8 bytes per record slot for 6 used: room for the alignment of the tails
-     * and for the filter's 16-byte loads past a short region */
-    if (dev_alloc(&ctx->d_rec, ctx->rec_total + 8) != hipSuccess ||
-	    dev_alloc(&ctx->d_acc_flat, ctx->frames_cap) != hipSuccess ||
+    if (alloc_lists(ctx) != hipSuccess ||
 	    dev_alloc(&ctx->d_known_bits, SORA_KNOWN_WORDS) != hipSuccess ||
-	    dev_alloc(&ctx->d_sq, ctx->sq_total) != hipSuccess ||
-	    dev_alloc(&ctx->d_acc, ctx->acc_total) != hipSuccess ||
-	    dev_alloc(&ctx->d_frames, ctx->frames_cap) != hipSuccess ||
 	    dev_alloc(&ctx->d_first_seen, SORA_ADDRESSES) != hipSuccess ||
 	    dev_alloc(&ctx->d_stats, (uint64_t) g * SORA_STAT_WORDS) != hipSuccess ||
 	    dev_alloc(&ctx->d_acc_offset, nr + 1) != hipSuccess ||
@@ -344,6 +408,11 @@ sora_adsb_scan(sora_adsb_ctx *ctx, const void *d_iq, size_t nbytes, int encoding
     if (n_tiles / ctx->scan_min_tiles < groups)
 	groups = n_tiles >= ctx->scan_min_tiles? (uint32_t) (n_tiles / ctx->scan_min_tiles) : 1;
 
+    /* the filter loads eight records at a time, aligned: a region holds at
+     * least eight (few, long regions when the record list is tiny) */
+    if (ctx->rec_total / groups < 8)
+	groups = ctx->rec_total / 8 > 0? (uint32_t) (ctx->rec_total / 8) : 1;
+
     /* a record carries its position relative to the first tile of its
      * workgroup's range in SORA_REGION_POS_BITS bits */
     if ((n_tiles / groups + 1) * sora_scan_tile_pos(encoding, (int) ctx->scan_variant) >=
@@ -360,17 +429,6 @@ sora_adsb_scan(sora_adsb_ctx *ctx, const void *d_iq, size_t nbytes, int encoding
     a.encoding = encoding;
     a.emit_all = ctx->cfg.emit_mode == SORA_EMIT_CANDIDATES;
     a.correct = (ctx->cfg.options & SORA_OPT_CORRECT_SINGLE_BIT) != 0;
-    /* the record buffer holds the 4-byte keys, then the 2-byte tails */
-    a.key = reinterpret_cast<uint32_t *>(ctx->d_rec);
-    a.tail = reinterpret_cast<uint16_t *>(reinterpret_cast<uint32_t *>(ctx->d_rec) +
-	    ((ctx->rec_total + 3) & ~3ull));	/* 16-byte aligned */
-    a.sq = ctx->d_sq;
-    a.rec_cap = (uint32_t) (ctx->rec_total / groups > 0x7fffffffull?
-	    0x7fffffffull : ctx->rec_total / groups);
-    if (a.rec_cap >= 8)
-	a.rec_cap &= ~7u;	/* the filter loads eight records at a time, aligned */
-    a.sq_cap = (uint32_t) (ctx->sq_total / groups > 0x7fffffffull?
-	    0x7fffffffull : ctx->sq_total / groups);
     a.rec_count = ctx->d_rec_count;
     a.sq_count = ctx->d_sq_count;
     a.stats = ctx->d_stats;
@@ -389,33 +447,29 @@ sora_adsb_scan(sora_adsb_ctx *ctx, const void *d_iq, size_t nbytes, int encoding
     r.encoding = encoding;
     r.emit_all = a.emit_all;
     r.groups = groups;
-    r.key = a.key;
-    r.tail = a.tail;
     r.n_tiles = n_tiles;
     r.tile_pos = sora_scan_tile_pos(encoding, (int) ctx->scan_variant);
     r.rec_count = ctx->d_rec_count;
-    r.rec_cap = a.rec_cap;
-    r.sq = ctx->d_sq;
     r.sq_count = ctx->d_sq_count;
-    r.sq_cap = a.sq_cap;
     r.first_seen = ctx->d_first_seen;
     r.known_bits = ctx->d_known_bits;
     r.filter_parts = sora_filter_parts(groups);
     r.regions = groups * r.filter_parts;
-    r.acc = ctx->d_acc;
     r.acc_count = ctx->d_acc_count;
-    r.acc_cap = (uint32_t) (ctx->acc_total / r.regions > 0x7fffffffull?
-	    0x7fffffffull : ctx->acc_total / r.regions);
     r.acc_offset = ctx->d_acc_offset;
-    r.acc_flat = ctx->d_acc_flat;
-    r.frames = ctx->d_frames;
-    r.frames_cap = ctx->frames_cap;
 
     ctx->groups = groups;
+    bind_lists(ctx);
     ctx->scanned = false;
     ctx->resolved = false;
     ctx->merged = merges;		/* else first_seen_kernel, before the first use */
     ctx->exported = false;
+    ctx->exchanged = false;
+    ctx->last.d_iq = d_iq;
+    ctx->last.nbytes = nbytes;
+    ctx->last.encoding = encoding;
+    ctx->last.base_position = base_position;
+    ctx->last.n_owned = n_owned;
 
     HIP_TRY(ctx, hipEventRecord(ctx->ev_scan_begin, ctx->stream));
     HIP_TRY(ctx, sora_launch_scan(&a, groups, (int) ctx->scan_variant, ctx->stream));
@@ -475,6 +529,7 @@ sora_adsb_copy_squitters(sora_adsb_ctx *ctx, void *d_dst, size_t cap_records) {
     if (rc != SORA_OK)
 	return rc;
     const size_t n = ctx->h_total[0] < cap_records? (size_t) ctx->h_total[0] : cap_records;
+    ctx->exchanged = true;
     if (n > 0)
 	HIP_TRY(ctx, hipMemcpyAsync(d_dst, ctx->d_export, n * sizeof(uint64_t),
 		hipMemcpyDeviceToDevice, ctx->stream));
@@ -506,6 +561,7 @@ sora_adsb_export_block(sora_adsb_ctx *ctx, void *d_block, size_t block_records) 
     uint64_t *blk = static_cast<uint64_t *>(d_block);
     HIP_TRY(ctx, sora_launch_export_first(&ctx->res, blk + 1, block_records - 1, blk,
 	    ctx->stream));
+    ctx->exchanged = true;
     return SORA_OK;
 }
 
@@ -613,6 +669,102 @@ fetch_counts(sora_adsb_ctx *ctx, bool *overflow) {
     return SORA_OK;
 }
 
+/*
+ * Counts on the host and, if a list overflowed, the chunk once more with
+ * lists of the sizes the counts ask for: the kernels count every record they
+ * would have written, so one re-run of the scan (records, squitters) and then
+ * one of the resolve (accepted records, frames) is enough.  The reference never
+ * drops a candidate (plane-iq.c:141-194); neither does a burst of candidates
+ * here.  Not repaired, *overflow stays set: SORA_OPT_FIXED_LISTS; a squitter
+ * list that overflowed after its (then truncated) export went to other shards.
+ * Needs the IQ buffer of the scan still in place (it is until the collect:
+ * the resolve reads it too).
+ */
+int
+ensure_complete(sora_adsb_ctx *ctx, bool *overflow) {
+    for (int attempt = 0; ; attempt++) {
+	int rc = fetch_counts(ctx, overflow);
+	if (rc != SORA_OK || !*overflow)
+	    return rc;
+	if ((ctx->cfg.options & SORA_OPT_FIXED_LISTS) != 0 || attempt >= 5)
+	    return SORA_OK;
+
+	const uint32_t g = ctx->groups, nr = ctx->res.regions;
+	uint64_t need_rec = 0, need_sq = 0, need_acc = 0, need_frames = 0;
+	for (uint32_t i = 0; i < g; i++) {
+	    if (ctx->h_counts[i] > need_rec)
+		need_rec = ctx->h_counts[i];
+	    if (ctx->h_counts[g + i] > need_sq)
+		need_sq = ctx->h_counts[g + i];
+	}
+	for (uint32_t i = 0; ctx->resolved && i < nr; i++) {
+	    if (ctx->h_counts[2 * g + i] > need_acc)
+		need_acc = ctx->h_counts[2 * g + i];
+	    need_frames += ctx->h_counts[2 * g + i];
+	}
+	const bool scan_over = need_rec > ctx->res.rec_cap || need_sq > ctx->res.sq_cap;
+	if (need_sq > ctx->res.sq_cap && ctx->exchanged)
+	    return SORA_OK;
+
+	/* a quarter more than was needed, shared out evenly like the lists are */
+	const auto grown = [](uint64_t per_region, uint32_t regions) {
+	    return ((per_region + per_region / 4 + 15) & ~7ull) * regions;
+	};
+	uint64_t rec_total = ctx->rec_total, sq_total = ctx->sq_total;
+	uint64_t acc_total = ctx->acc_total, frames_cap = ctx->frames_cap;
+	if (need_rec > ctx->res.rec_cap)
+	    rec_total = grown(need_rec, g);
+	if (need_sq > ctx->res.sq_cap)
+	    sq_total = grown(need_sq, g);
+	if (need_acc > ctx->res.acc_cap)
+	    acc_total = grown(need_acc, nr);
+	if (need_frames > frames_cap)
+	    frames_cap = need_frames + need_frames / 4 + 64;
+	if (scan_over && !ctx->cfg.emit_mode && acc_total < sq_total)
+	    acc_total = sq_total;	/* accepted frames are at least the squitters */
+	if (scan_over && ctx->cfg.emit_mode == SORA_EMIT_CANDIDATES && acc_total < rec_total)
+	    acc_total = rec_total;
+	if (frames_cap < acc_total && scan_over)
+	    frames_cap = acc_total;
+
+	/* every kernel that uses the old lists is done: fetch_counts waited */
+	const bool was_resolved = ctx->resolved;
+	free_lists(ctx);
+	ctx->rec_total = rec_total;
+	ctx->sq_total = sq_total;
+	ctx->acc_total = acc_total;
+	ctx->frames_cap = frames_cap;
+	uint64_t export_cap = sq_total < (1ull << 22)? sq_total : (1ull << 22);
+	if (export_cap > ctx->export_cap) {
+	    (void) hipFree(ctx->d_export);
+	    ctx->d_export = nullptr;
+	    ctx->export_cap = export_cap;
+	    if (dev_alloc(&ctx->d_export, export_cap) != hipSuccess)
+		return fail(ctx, SORA_ERR_NOMEM, "export list of %llu records",
+			(unsigned long long) export_cap);
+	}
+	if (alloc_lists(ctx) != hipSuccess) {
+	    ctx->scanned = ctx->resolved = false;
+	    return fail(ctx, SORA_ERR_NOMEM, "lists of %llu records, %llu squitters, %llu "
+		    "frames after an overflow", (unsigned long long) rec_total,
+		    (unsigned long long) sq_total, (unsigned long long) frames_cap);
+	}
+	ctx->regrows++;
+	if (scan_over) {
+	    const bool exchanged = ctx->exchanged;
+	    rc = sora_adsb_scan(ctx, ctx->last.d_iq, ctx->last.nbytes, ctx->last.encoding,
+		    ctx->last.base_position, ctx->last.n_owned);
+	    ctx->exchanged = exchanged;
+	    if (rc != SORA_OK)
+		return rc;
+	} else {
+	    bind_lists(ctx);
+	}
+	if (was_resolved && (rc = sora_adsb_resolve(ctx)) != SORA_OK)
+	    return rc;
+    }
+}
+
 int
 collect_common(sora_adsb_ctx *ctx, void *dst, size_t cap, size_t *n,
 	hipMemcpyKind kind) {
@@ -624,13 +776,13 @@ collect_common(sora_adsb_ctx *ctx, void *dst, size_t cap, size_t *n,
     if (!ctx->resolved)
 	return fail(ctx, SORA_ERR_STATE, "collect without a resolve");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    int rc = fetch_counts(ctx, &overflow);
+    int rc = ensure_complete(ctx, &overflow);
     if (rc != SORA_OK)
 	return rc;
     if (overflow)
 	return fail(ctx, SORA_ERR_OVERFLOW,
-		"a device list overflowed; raise max_candidates / max_squitters / "
-		"max_frames (see sora_adsb_get_counts)");
+		"a device list overflowed and could not be grown; raise max_candidates / "
+		"max_squitters / max_frames (see sora_adsb_get_counts)");
     const uint64_t total = ctx->h_total[1];
     *n = (size_t) total;
     const size_t take = total < cap? (size_t) total : cap;
@@ -664,7 +816,7 @@ sora_adsb_get_counts(sora_adsb_ctx *ctx, struct sora_adsb_counts *out) {
     if (!ctx->scanned)
 	return fail(ctx, SORA_ERR_STATE, "no scan to report on");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    int rc = fetch_counts(ctx, &overflow);
+    int rc = ensure_complete(ctx, &overflow);
     if (rc != SORA_OK)
 	return rc;
     out->positions = ctx->scan.n_scan;
@@ -792,6 +944,7 @@ sora_adsb_stream_begin(sora_adsb_ctx *ctx, int encoding, uint64_t block_samples,
 	return fail(ctx, SORA_ERR_NOMEM, "stream buffers (2 x %zu bytes pinned and "
 		"device, 2 x %zu bytes of frames)", in_bytes, out_bytes);
     }
+    s.out_cap[0] = s.out_cap[1] = ctx->frames_cap > 0? ctx->frames_cap : 1;
     s.active = true;
     return SORA_OK;
 }
@@ -824,8 +977,22 @@ sora_adsb_stream_next(sora_adsb_ctx *ctx, const sora_adsb_frame **frames, size_t
     /* the next block: read and copied while the kernels run */
     if (!s.last[cur] && (rc = stream_fill(ctx, cur ^ 1)) != SORA_OK)
 	return rc;
+    /* waits for the block; a list that overflowed is grown and the block run
+     * again (ensure_complete), and the pinned frame buffer follows */
+    bool overflow = false;
+    if ((rc = ensure_complete(ctx, &overflow)) != SORA_OK)
+	return rc;
+    if (!overflow && ctx->h_total[1] > s.out_cap[cur]) {
+	(void) hipHostFree(s.h_out[cur]);
+	s.h_out[cur] = nullptr;
+	s.out_cap[cur] = ctx->frames_cap;
+	if (hipHostMalloc(reinterpret_cast<void **>(&s.h_out[cur]),
+		(size_t) s.out_cap[cur] * sizeof(sora_adsb_frame), hipHostMallocDefault) != hipSuccess)
+	    return fail(ctx, SORA_ERR_NOMEM, "pinned buffer for %llu frames",
+		    (unsigned long long) s.out_cap[cur]);
+    }
     size_t got = 0;
-    rc = sora_adsb_collect(ctx, s.h_out[cur], (size_t) ctx->frames_cap, &got);
+    rc = sora_adsb_collect(ctx, s.h_out[cur], (size_t) s.out_cap[cur], &got);
     if (rc != SORA_OK)
 	return rc;
     *frames = s.h_out[cur];
@@ -866,6 +1033,11 @@ sora_adsb_debug_stamps(sora_adsb_ctx *ctx, uint64_t out[8]) {
     return SORA_OK;
 }
 #endif
+
+extern "C" int
+sora_adsb_list_regrows(const sora_adsb_ctx *ctx) {
+    return ctx != nullptr? (int) ctx->regrows : 0;
+}
 
 extern "C" int
 sora_adsb_synchronize(sora_adsb_ctx *ctx) {

@@ -44,7 +44,7 @@ usage(const char *argv0) {
 int
 main(int argc, char *argv[]) {
     const char *file_name = NULL;
-    int encoding = 0, adsb_decode = 0, c, flags = 0;
+    int encoding = 0, adsb_decode = 0, c, flags = 0, status;
     struct radio *radio = NULL;
     FILE *in = stdin;
 
@@ -103,9 +103,14 @@ main(int argc, char *argv[]) {
 	return EXIT_FAILURE;
     }
 
-    planes_main_loop_encoded(in, flags, encoding);
+    status = planes_main_loop_encoded(in, flags, encoding);
     fflush(stdout);
     if (radio != NULL)
 	radio->m->close(radio);
+    if (status != SORA_OK) {
+	/* the device failed: what was printed is not the whole capture */
+	fprintf(stderr, "%s: ADS-B decoding failed: %s\n", argv[0], sora_adsb_strerror(status));
+	return EXIT_FAILURE;
+    }
     return EXIT_SUCCESS;
 }

@@ -11,6 +11,16 @@
  * call, in position order -- the order in which the reference completes them
  * (plane-iq.c:76-83).
  *
+ * Which frames: the reference's iterator yields EVERY candidate, accepted or
+ * not (plane-iq.c:187-192), and so do plane_iq_state_new() and
+ * plane_iq_state_new_encoded(): a caller written against the reference (its own
+ * planes-main-loop.c linked against this library)
+ * sees what it saw before.  This library's planes_main_loop() drops rejected
+ * candidates without side effects (planes-main-loop.c:75-77), so it opens the
+ * state with plane_iq_state_new_accepted(): the device applies the acceptance
+ * rule and only the accepted frames cross PCIe.  SORA_ADSB_EMIT_ALL=1 / =0
+ * forces either behaviour for both.
+ *
  * Time: the reference stamps a candidate with gettimeofday() when it meets
  * the preamble (plane-iq.c:46), i.e. with the time at which it happened to
  * process that sample.  Here the stamp is stream time,
@@ -64,8 +74,8 @@ read_file(void *user, void *dst, size_t nbytes) {
     return fread(dst, 1, nbytes, (FILE *) user);
 }
 
-struct plane_iq_state *
-plane_iq_state_new_encoded(FILE *f, int encoding) {
+static struct plane_iq_state *
+state_new(FILE *f, int encoding, int emit_all) {
     struct plane_iq_state *st;
     struct sora_adsb_config cfg;
     const char *s;
@@ -98,16 +108,26 @@ plane_iq_state_new_encoded(FILE *f, int encoding) {
 
     memset(&cfg, 0, sizeof cfg);
     cfg.max_chunk_samples = st->block_samples + SORA_ADSB_HALO;
-    cfg.emit_mode = SORA_EMIT_ACCEPTED;
-    if ((s = getenv("SORA_ADSB_EMIT_ALL")) != NULL && atoi(s) != 0) {
-	cfg.emit_mode = SORA_EMIT_CANDIDATES;
-	cfg.max_candidates = cfg.max_chunk_samples / 2 + 1024;
-    }
+    if ((s = getenv("SORA_ADSB_EMIT_ALL")) != NULL && *s != '\0')
+	emit_all = atoi(s) != 0;
+    cfg.emit_mode = emit_all? SORA_EMIT_CANDIDATES : SORA_EMIT_ACCEPTED;
     /* opt-in extension: off, as in the reference */
     if ((s = getenv("SORA_ADSB_CORRECT")) != NULL && atoi(s) != 0)
 	cfg.options |= SORA_OPT_CORRECT_SINGLE_BIT;
-    /* a block cannot hold more accepted frames than one per 2 positions */
+    /* Candidate records: the bound outright -- p and p + 1 are never both
+     * candidates (plane-iq.c:173: m[p+1] < m[p], then m[p+2] > m[p+1]), so a
+     * block holds at most one per two positions: 8 bytes of device memory per
+     * slot, 128 MB for the default block.  Squitter and frame lists start at
+     * what busy airspace needs; the library grows a list that overflows and
+     * runs the block again (sora_adsb_gpu.h, SORA_OPT_FIXED_LISTS), so no
+     * input ends the stream early.  SORA_ADSB_MAX_CANDIDATES: tests of that. */
+    cfg.max_candidates = cfg.max_chunk_samples / 2 + 1024;
+    if ((s = getenv("SORA_ADSB_MAX_CANDIDATES")) != NULL && atoll(s) > 0)
+	cfg.max_candidates = (uint64_t) atoll(s);
     cfg.max_squitters = cfg.max_chunk_samples / 64 + 65536;
+    cfg.max_frames = emit_all? cfg.max_chunk_samples / 16 + 65536 : cfg.max_squitters;
+    if (cfg.max_frames > cfg.max_candidates && emit_all)
+	cfg.max_frames = cfg.max_candidates;
     s = getenv("SORA_ADSB_DEVICE");
     rc = sora_adsb_create(&st->ctx, s != NULL? atoi(s) : 0, &cfg);
     if (rc != SORA_OK) {
@@ -129,8 +149,18 @@ plane_iq_state_new_encoded(FILE *f, int encoding) {
 }
 
 struct plane_iq_state *
+plane_iq_state_new_encoded(FILE *f, int encoding) {
+    return state_new(f, encoding, 1);		/* every candidate, plane-iq.c:187-192 */
+}
+
+struct plane_iq_state *
+plane_iq_state_new_accepted(FILE *f, int encoding) {
+    return state_new(f, encoding, 0);
+}
+
+struct plane_iq_state *
 plane_iq_state_new(FILE *f) {
-    return plane_iq_state_new_encoded(f, SORA_ENC_UC8);	/* plane-iq.c:121-139 */
+    return state_new(f, SORA_ENC_UC8, 1);	/* uc8: plane-iq.c:121-139 */
 }
 
 void

@@ -142,6 +142,69 @@ plane_set_lookup_create(struct plane_set *ps, uint32_t address) {
     return pl;
 }
 
+/* plane.h:18 over the open-addressing table: the occupied slots in table order */
+struct set_iterator {
+    struct iterator it;			/* first: the two pointers convert */
+    struct plane_set *ps;
+    size_t at;				/* next occupied slot, or ps->size */
+};
+
+static void
+set_iterator_seek(struct set_iterator *si) {
+    while (si->at < si->ps->size && si->ps->slot[si->at] == NULL)
+	si->at++;
+}
+
+static int
+set_iterator_is_at_end(struct iterator *it) {
+    const struct set_iterator *si = (struct set_iterator *) it;
+
+    return si->at >= si->ps->size;
+}
+
+static void
+set_iterator_next_pair(struct iterator *it, const void **key, void **data) {
+    struct set_iterator *si = (struct set_iterator *) it;
+
+    if (si->at >= si->ps->size) {
+	*key = *data = NULL;		/* hash.c:385-386 */
+	return;
+    }
+    *key = (const void *) (intptr_t) si->ps->slot[si->at]->address;
+    *data = si->ps->slot[si->at];
+    si->at++;
+    set_iterator_seek(si);
+}
+
+static void *
+set_iterator_next(struct iterator *it) {
+    const void *key;
+    void *data;
+
+    set_iterator_next_pair(it, &key, &data);
+    return data;
+}
+
+static void
+set_iterator_free(struct iterator *it) {
+    free(it);
+}
+
+struct iterator *
+plane_set_iterate(struct plane_set *ps) {
+    struct set_iterator *si = calloc(1, sizeof *si);
+
+    if (si == NULL)
+	abort();
+    si->it.is_at_end = set_iterator_is_at_end;
+    si->it.next = set_iterator_next;
+    si->it.next_pair = set_iterator_next_pair;
+    si->it.free = set_iterator_free;
+    si->ps = ps;
+    set_iterator_seek(si);
+    return &si->it;
+}
+
 struct plane *
 plane_clone(struct plane *pl) {
     struct plane *copy = plane_make(pl->address);

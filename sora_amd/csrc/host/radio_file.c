@@ -105,6 +105,29 @@ static struct radio_methods file_methods = {
     set_frequency, get_frequency, set_rate, get_rate, file_read, file_position, file_close
 };
 
+/* the vtable core of radio.c:18-86: a frontend leaves the slots it does not
+ * implement NULL and radio_init() fills them in */
+static int no_set_frequency(struct radio *r, t_frequency f) { (void) r; (void) f; return -1; }
+static int no_get_frequency(struct radio *r, t_frequency *f) { (void) r; (void) f; return -1; }
+static int no_set_rate(struct radio *r, unsigned long s) { (void) r; (void) s; return -1; }
+static int no_get_rate(struct radio *r, unsigned long *s) { (void) r; (void) s; return -1; }
+static ssize_t no_read(struct radio *r, struct sample *b, size_t n)
+{ (void) r; (void) b; (void) n; return -1; }
+static off_t no_position(struct radio *r) { (void) r; return 0; }
+static void no_close(struct radio *r) { (void) r; }
+
+void
+radio_init(struct radio *r, struct radio_methods *m) {
+    if (m->set_frequency == NULL) m->set_frequency = no_set_frequency;
+    if (m->get_frequency == NULL) m->get_frequency = no_get_frequency;
+    if (m->set_sample_rate == NULL) m->set_sample_rate = no_set_rate;
+    if (m->get_sample_rate == NULL) m->get_sample_rate = no_get_rate;
+    if (m->read == NULL) m->read = no_read;
+    if (m->get_file_position == NULL) m->get_file_position = no_position;
+    if (m->close == NULL) m->close = no_close;
+    r->m = m;
+}
+
 struct radio *
 radio_file_open(const char *name, int encoding) {
     struct file_radio *fr = calloc(1, sizeof *fr);
@@ -120,7 +143,7 @@ radio_file_open(const char *name, int encoding) {
     }
     fr->rate = 1;				/* radio-file.c:52 */
     fr->encoding = encoding;
-    fr->radio.m = &file_methods;
+    radio_init(&fr->radio, &file_methods);	/* radio-file.c:55 */
     return &fr->radio;
 }
 

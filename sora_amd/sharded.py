@@ -114,6 +114,14 @@ class ShardedDecoder:
         self.block = max(2, int(exchange_records))
         self.d_blk = torch.zeros(self.block, dtype=torch.int64, device=device)
         self.d_blk_all = torch.zeros(world * self.block, dtype=torch.int64, device=device)
+        # gloo moves host memory: with device contexts under a gloo group (several
+        # ranks sharing one GPU, which RCCL refuses; tests) the 64 KB block is
+        # staged through pinned host memory at the cost of one stream wait
+        self.stage_exchange = self.cuda and dist.get_backend(group) == "gloo"
+        if self.stage_exchange:
+            self.h_blk = torch.zeros(self.block, dtype=torch.int64, pin_memory=True)
+            self.h_blk_all = torch.zeros(world * self.block, dtype=torch.int64,
+                                         pin_memory=True)
         self.h_exported = torch.zeros(world, dtype=torch.int64, pin_memory=self.cuda)
         self.counts = torch.zeros(world, dtype=torch.int64, device=device)
         self.d_out = torch.zeros(self.max_frames * FRAME_BYTES, dtype=torch.uint8,
@@ -189,9 +197,11 @@ class ShardedDecoder:
         return contextlib.nullcontext()
 
     def _all_counts(self, k):
-        mine = torch.tensor([k], dtype=torch.int64, device=self.device)
-        dist.all_gather_into_tensor(self.counts, mine, group=self.group)
-        return [int(x) for x in self.counts.tolist()]
+        dev = "cpu" if self.stage_exchange else self.device
+        mine = torch.tensor([k], dtype=torch.int64, device=dev)
+        counts = self.counts.cpu() if self.stage_exchange else self.counts
+        dist.all_gather_into_tensor(counts, mine, group=self.group)
+        return [int(x) for x in counts.tolist()]
 
     def _spin(self, ready, what):
         t0 = time.monotonic()
@@ -215,7 +225,13 @@ class ShardedDecoder:
         ctx, world = self.ctx, self.world
         with self._on_stream():
             ctx.export_block(self.d_blk, self.block)
-            dist.all_gather_into_tensor(self.d_blk_all, self.d_blk, group=self.group)
+            if self.stage_exchange:
+                self.h_blk.copy_(self.d_blk, non_blocking=True)
+                torch.cuda.current_stream().synchronize()
+                dist.all_gather_into_tensor(self.h_blk_all, self.h_blk, group=self.group)
+                self.d_blk_all.copy_(self.h_blk_all, non_blocking=True)
+            else:
+                dist.all_gather_into_tensor(self.d_blk_all, self.d_blk, group=self.group)
             ctx.add_known_blocks(self.d_blk_all, world, self.block, skip_block=self.rank)
             ctx.resolve()
             # what every rank exported, for the overflow check in finish()
@@ -287,7 +303,13 @@ class ShardedDecoder:
             raise RuntimeError(f"{max(ns)} frames exceed max_frames")
         self.ns = ns
         m = max(ns) * FRAME_BYTES
-        if m:
+        if m and self.stage_exchange:           # gloo: through host memory
+            mine = self.d_out[:m].cpu()
+            parts = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
+            dist.gather(mine, parts, dst=0, group=self.group)
+            for r in range(world if rank == 0 else 0):
+                self.d_gather[r][:m].copy_(parts[r])
+        elif m:
             dist.gather(self.d_out[:m],
                         [g[:m] for g in self.d_gather] if rank == 0 else None,
                         dst=0, group=self.group)

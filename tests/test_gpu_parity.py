@@ -30,6 +30,16 @@ def gpu_frames(raw, encoding=ENC_UC8, emit=EMIT_CANDIDATES, host=False, **kw):
     return frames_as_dicts(frames), counts
 
 
+def dense_candidates(n):
+    """A period-10 magnitude pattern with a preamble hit at every tenth position:
+    1613 candidates per 16128-position tile, more than the scan kernel's small
+    hit queue (1536) holds."""
+    v = np.array([9, 1, 8, 1, 2, 2, 2, 5, 1, 3], dtype=np.int64)
+    iq = np.full(2 * n, 128, dtype=np.uint8)
+    iq[0::2] = 128 + 10 * v[np.arange(n) % 10]
+    return iq.tobytes()
+
+
 @pytest.mark.parametrize("name", GOLDEN_NAMES)
 def test_golden_candidates(name):
     raw, cands, _ = load_golden(name)
@@ -205,15 +215,97 @@ def test_shard_exchange_blocks_equal_whole(block):
     assert_same_frames(got, want)
 
 
-def test_overflow_is_reported():
+def test_overflow_is_reported_with_fixed_lists():
+    """SORA_OPT_FIXED_LISTS: the lists never change, an overflow is an error."""
     rng = np.random.default_rng(1)
     raw = rng.integers(0, 256, size=2 * 200000, dtype=np.uint8).tobytes()
-    with AdsbContext(200000, max_candidates=100) as ctx:
+    with AdsbContext(200000, max_candidates=100, fixed_lists=True) as ctx:
         ctx.submit_host(raw, ENC_UC8)
         with pytest.raises(sora_amd.SoraError) as e:
             ctx.collect()
         assert e.value.code == sora_amd._lib.ERR_OVERFLOW
-        assert ctx.counts()["overflow"]
+        assert ctx.counts()["overflow"] and ctx.list_regrows() == 0
+
+
+@pytest.mark.parametrize("small", ["max_candidates", "max_squitters", "max_frames", "all"])
+@pytest.mark.parametrize("emit", [EMIT_ACCEPTED, EMIT_CANDIDATES])
+def test_overflow_reruns_the_chunk(small, emit):
+    """Default: a list that overflowed is grown and the chunk run again -- the
+    reference never drops a candidate (plane-iq.c:141-194).  Each list on its own
+    and all three together, far too small; dense traffic so that the squitter
+    and frame lists matter."""
+    p = synth.default_params(2, n_samples=700000, mean_gap=400, reply_permille=300,
+                             unknown_permille=200, n_icao=6, seed=41)
+    raw = synth.fill_host(p.n_samples, p.encoding, p.seed, synth.make_frames(p)).tobytes()
+    raw = dense_candidates(60000) + raw              # a burst in the first regions only
+    n = len(raw) // 2
+    want = ob.scan(raw)
+    if emit == EMIT_ACCEPTED:
+        want = [c for c in want if c["accepted"]]
+    assert sum(1 for c in want if c["accepted"]) > 1000
+    sizes = {k: 16 for k in ("max_candidates", "max_squitters", "max_frames")
+             if small in (k, "all")}
+    with AdsbContext(n, emit_mode=emit, **sizes) as ctx:
+        for again in range(2):                       # the second pass fits as it is
+            ctx.reset()
+            ctx.submit_host(raw, ENC_UC8)
+            got = frames_as_dicts(ctx.collect())
+            counts = ctx.counts()
+            assert_same_frames(got, want)
+            assert not counts["overflow"] and counts["frames"] == len(want)
+            assert ctx.list_regrows() >= 1
+            if again == 0:
+                first = ctx.list_regrows()
+        assert ctx.list_regrows() == first
+    # counts() alone triggers the re-run too (ShardedDecoder asks for the frame
+    # count before it collects)
+    with AdsbContext(n, emit_mode=emit, **sizes) as ctx:
+        buf = DeviceBuffer.from_host(raw + bytes(16))
+        ctx.submit_device(buf, len(raw), ENC_UC8)
+        assert ctx.counts()["frames"] == len(want)
+        assert_same_frames(frames_as_dicts(ctx.collect()), want)
+
+
+def test_overflow_reruns_a_streamed_block():
+    """The same through sora_adsb_stream_*: the pinned frame buffers follow."""
+    p = synth.default_params(2, n_samples=500000, mean_gap=300, reply_permille=300,
+                             unknown_permille=200, n_icao=6, seed=43)
+    raw = synth.fill_host(p.n_samples, p.encoding, p.seed, synth.make_frames(p)).tobytes()
+    want = [c for c in ob.scan(raw) if c["accepted"]]
+    with AdsbContext(120000 + 239, max_candidates=16, max_squitters=16, max_frames=16) as ctx:
+        got = frames_as_dicts(np.concatenate(list(ctx.stream(raw, ENC_UC8, 120000))))
+        assert ctx.list_regrows() >= 2
+    assert_same_frames(got, want)
+    want = ob.scan(raw)
+    with AdsbContext(120000 + 239, emit_mode=EMIT_CANDIDATES, max_candidates=16,
+                     max_squitters=16, max_frames=16) as ctx:
+        got = frames_as_dicts(np.concatenate(list(ctx.stream(raw, ENC_UC8, 120000))))
+    assert_same_frames(got, want)
+
+
+def test_overflow_after_an_export_is_reported():
+    """A squitter list that overflowed after its export went to other shards
+    cannot be repaired locally: they merged a truncated list."""
+    import torch
+    p = synth.default_params(2, n_samples=400000, mean_gap=400, n_icao=6, seed=44)
+    raw = synth.fill_host(p.n_samples, p.encoding, p.seed, synth.make_frames(p)).tobytes()
+    buf = DeviceBuffer.from_host(raw + bytes(16))
+    blk = torch.zeros(64, dtype=torch.int64, device="cuda")
+    with AdsbContext(p.n_samples, max_squitters=16) as ctx:
+        ctx.scan(buf, len(raw), ENC_UC8)
+        ctx.export_block(blk, 64)
+        ctx.resolve()
+        with pytest.raises(sora_amd.SoraError) as e:
+            ctx.collect()
+        assert e.value.code == sora_amd._lib.ERR_OVERFLOW
+    # the record and frame lists are repaired even then: the export was whole
+    want = [c for c in ob.scan(raw) if c["accepted"]]
+    with AdsbContext(p.n_samples, max_candidates=16, max_frames=16) as ctx:
+        ctx.scan(buf, len(raw), ENC_UC8)
+        ctx.export_block(blk, 64)
+        ctx.resolve()
+        assert_same_frames(frames_as_dicts(ctx.collect()), want)
+        assert ctx.list_regrows() >= 1
 
 
 def test_bad_arguments():
@@ -552,16 +644,6 @@ def test_config2_full_size_properties():
         parts.append(ctx.collect())
         ctx.close()
     assert np.concatenate(parts).tobytes() == a.tobytes()
-
-
-def dense_candidates(n):
-    """A period-10 magnitude pattern with a preamble hit at every tenth position:
-    1613 candidates per 16128-position tile, more than the scan kernel's small
-    hit queue (1536) holds."""
-    v = np.array([9, 1, 8, 1, 2, 2, 2, 5, 1, 3], dtype=np.int64)
-    iq = np.full(2 * n, 128, dtype=np.uint8)
-    iq[0::2] = 128 + 10 * v[np.arange(n) % 10]
-    return iq.tobytes()
 
 
 def test_more_hits_than_the_small_queue():

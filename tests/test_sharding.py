@@ -1,9 +1,18 @@
-"""CPU tier: the N>1 path (sora_amd/sharded.py) with world_size 2 over gloo.
+"""The N>1 path (sora_amd/sharded.py) with world_size 2 over gloo.
 
-The per-rank device context is replaced by an oracle-backed stand-in with the
-same interface (tests may use the oracle; the product never does), so what is
-tested is what sharded.py owns: the shard plan and its halos, the squitter
-record exchange, the first-seen rule across shards, and the rank-ordered gather.
+CPU tier: the per-rank device context is replaced by an oracle-backed stand-in
+with the same interface (tests may use the oracle; the product never does), so
+what is tested is what sharded.py owns: the shard plan and its halos, the
+squitter record exchange, the first-seen rule across shards, and the
+rank-ordered gather.
+
+GPU tier (-m gpu): the same two processes, each with a REAL AdsbContext on the
+one GPU of the box and the real ShardedDecoder(gather="shm") -- the /dev/shm
+header and spin protocol, the pinned staging copy, two decoders interleaved the
+way bench.py pipelines them -- against the whole-capture oracle list.  RCCL
+refuses two ranks on one device, so the 64 KB exchange block travels over gloo
+(staged through pinned host memory, sharded.py); everything else is the code
+that runs with one rank per GPU.
 """
 import os
 import socket
@@ -101,19 +110,33 @@ class OracleContext:
         return len(self.frames)
 
 
-def _worker(rank, world, port, raw, result_path, gather, exchange_records=64):
+def _worker(rank, world, port, raw, result_path, gather, exchange_records=64, gpu=False,
+            max_frames=20000, ctx_kw=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         total = len(raw) // 2
         first, owned, local = plan_shards(total, world)[rank]
-        shard = torch.frombuffer(bytearray(raw[2 * first:2 * (first + local)]),
+        shard = torch.frombuffer(bytearray(raw[2 * first:2 * (first + local)] + bytes(16)),
                                  dtype=torch.uint8)
         # two decoders interleaved the way bench.py pipelines them
-        decs = [ShardedDecoder(OracleContext(), rank, world, torch.device("cpu"), 20000,
-                               gather=gather, exchange_records=exchange_records)
-                for _ in range(2)]
+        if gpu:
+            from sora_amd import AdsbContext
+            torch.cuda.set_device(0)
+            dev = torch.device("cuda", 0)
+            shard = shard.to(dev)
+            streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+            ctxs = [AdsbContext(local, device=0, stream=st.cuda_stream, **(ctx_kw or {}))
+                    for st in streams]
+            decs = [ShardedDecoder(c, rank, world, dev, max_frames, gather=gather, stream=st,
+                                   exchange_records=exchange_records)
+                    for c, st in zip(ctxs, streams)]
+        else:
+            decs = [ShardedDecoder(OracleContext(), rank, world, torch.device("cpu"),
+                                   max_frames, gather=gather,
+                                   exchange_records=exchange_records)
+                    for _ in range(2)]
         args = (shard, 2 * local, ob.ENC_UC8, first, owned)
         decs[0].begin(*args)
         decs[0].exchange()
@@ -129,6 +152,9 @@ def _worker(rank, world, port, raw, result_path, gather, exchange_records=64):
             assert np.array_equal(decs[0].frames(), decs[1].frames())
             assert len(decs[0].frames()) == n
             np.save(result_path, decs[0].frames().copy())
+        if gpu:
+            with open(f"{result_path}.{rank}.regrows", "w") as fh:
+                fh.write(str(sum(c.list_regrows() for c in ctxs)))
         for d in decs:
             d.close()
     finally:
@@ -185,9 +211,9 @@ def test_local_decoder_phases():
     assert [int(f["position"]) for f in dec.frames()] == [c["position"] for c in want]
 
 
-def _overflow_worker(rank, world, port, raw, path):
+def _overflow_worker(rank, world, port, raw, path, gpu=False):
     try:
-        _worker(rank, world, port, raw, path, "shm", exchange_records=3)
+        _worker(rank, world, port, raw, path, "shm", exchange_records=3, gpu=gpu)
     except RuntimeError as e:
         assert "exchange records exceed" in str(e)
         with open(f"{path}.{rank}.raised", "w") as fh:
@@ -206,3 +232,56 @@ def test_exchange_block_overflow_is_reported(tmp_path):
     out = str(tmp_path / "frames.npy")
     mp.spawn(_overflow_worker, args=(2, port, raw, out), nprocs=2, join=True)
     assert os.path.exists(out + ".0.raised") and os.path.exists(out + ".1.raised")
+
+
+# ---- GPU tier: two processes, real contexts, one device ----------------------
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _same_as_oracle(got, want):
+    from conftest import assert_same_frames, frames_as_dicts
+    assert_same_frames(frames_as_dicts(got), want)
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("gather", ["shm", "collective"])
+def test_two_gpu_processes_equal_the_whole_capture(tmp_path, gather):
+    """BASELINE.json configs[2] with two ranks: haloed time shards, the squitter
+    exchange, every rank's frames into the node's host segment, rank 0 reads the
+    position-sorted whole; bit-exact with the oracle on the unsharded capture."""
+    p = synth.default_params(2, n_samples=1600000, mean_gap=700, reply_permille=300,
+                             unknown_permille=250, n_icao=9, seed=23)
+    raw = synth.fill_host(p.n_samples, p.encoding, p.seed, synth.make_frames(p)).tobytes()
+    want = [c for c in ob.scan(raw) if c["accepted"]]
+    half = plan_shards(p.n_samples, 2)[1][0]
+    # addresses first seen in shard 0 whose replies lie in shard 1: the rule
+    # crosses the boundary
+    assert [c for c in want if c["position"] >= half and c["df"] not in (11, 17, 18)]
+    out = str(tmp_path / "frames.npy")
+    mp.spawn(_worker, args=(2, _free_port(), raw, out, gather, 64, True), nprocs=2, join=True)
+    _same_as_oracle(np.load(out), want)
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_two_gpu_processes_small_lists_and_block_overflow(tmp_path):
+    """Record and frame lists far too small on both ranks: each rank re-runs its
+    shard locally (the squitter export was whole), the result is still exact.
+    And an exchange block too small for the addresses raises on BOTH ranks."""
+    p = synth.default_params(2, n_samples=900000, mean_gap=700, reply_permille=300,
+                             unknown_permille=250, n_icao=6, seed=29)
+    raw = synth.fill_host(p.n_samples, p.encoding, p.seed, synth.make_frames(p)).tobytes()
+    want = [c for c in ob.scan(raw) if c["accepted"]]
+    out = str(tmp_path / "frames.npy")
+    mp.spawn(_worker, args=(2, _free_port(), raw, out, "shm", 64, True, 20000,
+                            {"max_candidates": 16, "max_frames": 16}), nprocs=2, join=True)
+    _same_as_oracle(np.load(out), want)
+    assert all(int(open(f"{out}.{r}.regrows").read()) >= 2 for r in range(2))
+    out2 = str(tmp_path / "frames2.npy")
+    mp.spawn(_overflow_worker, args=(2, _free_port(), raw, out2, True), nprocs=2, join=True)
+    assert os.path.exists(out2 + ".0.raised") and os.path.exists(out2 + ".1.raised")
