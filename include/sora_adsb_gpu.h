@@ -271,6 +271,49 @@ int sora_adsb_last_scan_ms(sora_adsb_ctx *ctx, float *ms);
 const char *sora_adsb_scan_kernel_name(const sora_adsb_ctx *ctx, int encoding);
 
 /*
+ * scan + resolve + frames to a device buffer -- sora_adsb_submit_device()
+ * followed by sora_adsb_collect_device() -- for callers that CANNOT ALLOCATE:
+ * code under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc.  It has no counterpart in the reference (whose demodulator holds a
+ * 4096-float ring and a malloc'ed list of in-flight messages,
+ * plane-iq.c:22-56) and none among the reference's callers; it exists for those
+ * callers alone.  It needs no context: every list the kernels use lives in one
+ * static device array of the library, SORA_NOALLOC_SCRATCH_BYTES (38 MiB) per
+ * GPU the entry point has run on, held until the process ends.  The call
+ * allocates nothing, frees nothing and never waits: it queues its kernels on
+ * `stream` (a hipStream_t; NULL = the null stream) and returns.
+ *
+ * At most SORA_NOALLOC_MAX_SAMPLES samples per call (one second at 2 MS/s);
+ * more is SORA_ERR_INVALID.  Arguments as sora_adsb_submit_device; emit_mode
+ * and options as in sora_adsb_config (SORA_OPT_FIXED_LISTS is implied).
+ * keep_known = 0 starts from an empty set of known addresses, like a new
+ * context; != 0 keeps the set the previous call on this GPU left, so that
+ * consecutive chunks of one stream (base_position advancing, 239-sample halo
+ * behind every chunk but the last) decode like one capture.
+ * d_frames: DEVICE memory for cap_frames frames, in increasing position.
+ * d_status: DEVICE memory for two uint64_t: [0] the number of frames available
+ * (at most cap_frames are written), [1] zero, or SORA_NOALLOC_* flags of what
+ * did not fit -- the frame list is then incomplete.  The record list is sized
+ * for the physical bound (one candidate per two positions) and cannot overflow.
+ *
+ * All calls on one GPU share that GPU's array: calls that overlap on one GPU
+ * (two streams, two threads) race; serialize them.  The first call on a GPU
+ * looks the array up (hipGetSymbolAddress) and reads the device properties:
+ * make it outside a graph capture (nbytes = 0 will do).
+ */
+#define SORA_NOALLOC_MAX_SAMPLES	(1u << 21)
+#define SORA_NOALLOC_SCRATCH_BYTES	(38u << 20)
+#define SORA_NOALLOC_MAX_ADDRESSES	65536	/* distinct known addresses */
+#define SORA_NOALLOC_RECORDS_FULL	0x01	/* cannot happen; checked all the same */
+#define SORA_NOALLOC_SQUITTERS_FULL	0x02	/* > 2^18 clean squitters in the chunk */
+#define SORA_NOALLOC_FRAMES_FULL	0x04	/* more frames than cap_frames (or 2^20) */
+#define SORA_NOALLOC_ADDRESSES_FULL	0x08	/* > SORA_NOALLOC_MAX_ADDRESSES known */
+int sora_adsb_decode_noalloc(int device, void *stream, const void *d_iq, size_t nbytes,
+	int encoding, uint64_t base_position, uint64_t n_owned, int emit_mode,
+	int options, int keep_known, struct sora_adsb_frame *d_frames, size_t cap_frames,
+	uint64_t *d_status);
+
+/*
  * Magnitudes only (row a1), for the 1-ulp check north_star asks for:
  * m[i] as float for every sample, DEVICE in, DEVICE out.
  */

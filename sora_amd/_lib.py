@@ -25,6 +25,8 @@ FRAME_LONG, FRAME_SQUITTER, FRAME_ACCEPTED, FRAME_CORRECTED = 1, 2, 4, 8
 OPT_CORRECT_SINGLE_BIT = 1
 OPT_FIXED_LISTS = 2
 WINDOW, HALO = 240, 239
+NOALLOC_MAX_SAMPLES = 1 << 21
+NOALLOC_SCRATCH_BYTES = 38 << 20
 
 
 class SoraError(RuntimeError):
@@ -151,6 +153,9 @@ _SIGNATURES = {
     "sora_adsb_synchronize": (C.c_int, [C.c_void_p]),
     "sora_adsb_last_scan_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "sora_adsb_scan_kernel_name": (C.c_char_p, [C.c_void_p, C.c_int]),
+    "sora_adsb_decode_noalloc": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t,
+                                           C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_int,
+                                           C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "sora_adsb_magnitude": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int,
                                       C.c_void_p]),
     "sora_adsb_device_alloc": (C.c_int, [C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]),

@@ -76,10 +76,18 @@ struct sora_resolve_args {
     const uint64_t *sq;
     const uint32_t *sq_count;
     uint32_t sq_cap;
-    uint64_t *first_seen;	/* [1 << 24] smallest global position, or ~0 */
+    uint64_t *first_seen;	/* [1 << 24] smallest global position, or ~0
+				 * (hashed form: [seen_mask + 1] values, below) */
     uint32_t *known_bits;	/* [SORA_KNOWN_WORDS] bitmap of the addresses in
 				 * first_seen, then its 2^17-bit fold
 				 * (bit addr & 0x1ffff) for the filter's LDS */
+    /* Hashed form of the first-seen table, for sora_adsb_decode_noalloc() whose
+     * scratch cannot hold 2^24 entries: open addressing over seen_mask + 1 slots,
+     * seen_keys[slot] = address or SORA_SEEN_EMPTY, first_seen[slot] its position.
+     * NULL in every context: they use the direct table. */
+    uint32_t *seen_keys;
+    uint32_t seen_mask;
+    uint32_t *seen_fail;	/* set when the table is full (an address was dropped) */
     uint32_t regions;		/* accepted regions: groups * filter_parts */
     uint32_t filter_parts;	/* sora_filter_parts(groups) */
     uint64_t *acc;		/* [regions][acc_cap] accepted records */
@@ -90,6 +98,8 @@ struct sora_resolve_args {
     struct sora_adsb_frame *frames;
     uint64_t frames_cap;
 };
+
+#define SORA_SEEN_EMPTY		0xffffffffu
 
 #define SORA_REGION_POS_BITS	22	/* a workgroup's tile range spans fewer positions */
 
@@ -121,6 +131,10 @@ hipError_t sora_launch_export_first(const struct sora_resolve_args *a, uint64_t 
 	uint64_t dst_cap, uint64_t *counter, hipStream_t stream);
 hipError_t sora_launch_filter(const struct sora_resolve_args *a,
 	hipStream_t stream);
+/* sora_adsb_decode_noalloc(): frames available and overflow flags of the run
+ * into status[0..1], on the device (SORA_NOALLOC_* in sora_adsb_gpu.h) */
+hipError_t sora_launch_noalloc_status(const struct sora_resolve_args *a,
+	uint64_t cap_frames, uint64_t *status, hipStream_t stream);
 hipError_t sora_launch_scan_counts(const uint32_t *counts, uint32_t cap,
 	uint64_t *offsets, uint32_t n, hipStream_t stream);
 uint32_t sora_filter_parts(uint32_t groups);		/* accepted regions per scan region */

@@ -840,9 +840,64 @@ note_known(uint64_t *first_seen, uint32_t *known_bits, uint32_t addr,
     }
 }
 
+/*
+ * The same set in the hashed form (sora_resolve_args::seen_keys): linear
+ * probing, a slot is claimed by one atomicCAS on its key (keys only ever go
+ * from empty to an address), the position is an atomicMin like above.  A full
+ * table drops the address and says so in *seen_fail.
+ */
+__device__ __forceinline__ uint32_t
+seen_slot(uint32_t addr, uint32_t mask) {
+    return ((addr * 0x9e3779b1u) >> 8) & mask;
+}
+
+__device__ __forceinline__ void
+note_known_hashed(const sora_resolve_args &a, uint32_t addr, uint64_t position) {
+    uint32_t slot = seen_slot(addr, a.seen_mask);
+    bool placed = false;
+    for (uint32_t probe = 0; probe <= a.seen_mask; probe++) {
+	uint32_t k = __hip_atomic_load(&a.seen_keys[slot], __ATOMIC_RELAXED,
+		__HIP_MEMORY_SCOPE_AGENT);
+	if (k == SORA_SEEN_EMPTY)
+	    k = atomicCAS(&a.seen_keys[slot], SORA_SEEN_EMPTY, addr);
+	if (k == SORA_SEEN_EMPTY || k == addr) {
+	    atomicMin(reinterpret_cast<unsigned long long *>(&a.first_seen[slot]),
+		    (unsigned long long) position);
+	    placed = true;
+	    break;
+	}
+	slot = (slot + 1) & a.seen_mask;
+    }
+    if (!placed) {
+	atomicOr(a.seen_fail, 1u);
+	return;			/* not in the bitmap either: its replies are dropped */
+    }
+    const uint32_t bit = 1u << (addr & 31);
+    if ((atomicOr(&a.known_bits[addr >> 5], bit) & bit) == 0) {
+	uint32_t *fold = a.known_bits + SORA_KNOWN_BITMAP_WORDS;
+	atomicOr(&fold[(addr & ((1u << SORA_KNOWN_FOLD_BITS) - 1)) >> 5], bit);
+    }
+}
+
+/* first-seen position of a known address (its bit is set in the bitmap) */
+__device__ __forceinline__ uint64_t
+seen_lookup_hashed(const sora_resolve_args &a, uint32_t addr) {
+    uint32_t slot = seen_slot(addr, a.seen_mask);
+    for (uint32_t probe = 0; probe <= a.seen_mask; probe++) {
+	const uint32_t k = a.seen_keys[slot];
+	if (k == addr)
+	    return a.first_seen[slot];
+	if (k == SORA_SEEN_EMPTY)
+	    break;
+	slot = (slot + 1) & a.seen_mask;
+    }
+    return ~0ull;
+}
+
 /* one block per workgroup region of the scan (one wave per region, several
  * regions per wave, measured slower: 0.082 -> 0.107 ms, the kernel waits for the
  * few hundred hot lines of first_seen, not for block starts) */
+template <bool kHashed>
 __global__ void
 first_seen_kernel(sora_resolve_args a) {
     const uint32_t group = blockIdx.x;
@@ -853,8 +908,11 @@ first_seen_kernel(sora_resolve_args a) {
 	n = a.sq_cap;
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
 	uint64_t r = sq[i];
-	note_known(a.first_seen, a.known_bits, sora_rec_addr(r),
-		a.base_position + sora_rec_pos(r));
+	if constexpr (kHashed)
+	    note_known_hashed(a, sora_rec_addr(r), a.base_position + sora_rec_pos(r));
+	else
+	    note_known(a.first_seen, a.known_bits, sora_rec_addr(r),
+		    a.base_position + sora_rec_pos(r));
     }
 }
 
@@ -1008,6 +1066,7 @@ constexpr int kFilterUnroll = 8;
  * many parts (24 waves per CU of a 256-CU part) */
 constexpr uint32_t kFilterTargetParts = 6144;
 
+template <bool kHashed>
 __global__ void __launch_bounds__(kSmall)
 filter_kernel(sora_resolve_args a) {
     /* the 2^17-bit fold of the known-address bitmap: with a few hundred planes
@@ -1087,7 +1146,8 @@ filter_kernel(sora_resolve_args a) {
 		if (known)
 		    known = (a.known_bits[addr >> 5] >> (addr & 31)) & 1;
 		if (known)
-		    known = a.first_seen[addr] < a.base_position + pos;
+		    known = (kHashed? seen_lookup_hashed(a, addr) : a.first_seen[addr]) <
+			    a.base_position + pos;
 		if (known)
 		    r[u] |= SORA_REC_ACCEPTED << 60;
 		kept = known || a.emit_all;
@@ -1432,6 +1492,43 @@ finalize_kernel(sora_resolve_args a) {
     }
 }
 
+/*
+ * sora_adsb_decode_noalloc(): what a context finds out on the host from the
+ * per-region counters (fetch_counts in adsb_gpu.hip), found out on the device
+ * instead, since that entry point never waits: status[0] = frames available,
+ * status[1] = SORA_NOALLOC_* flags of what did not fit.
+ */
+__global__ void __launch_bounds__(kSmall)
+noalloc_status_kernel(sora_resolve_args a, uint64_t cap_frames, uint64_t *status) {
+    __shared__ uint32_t s_flags;
+    if (threadIdx.x == 0)
+	s_flags = 0;
+    __syncthreads();
+    uint32_t flags = 0;
+    for (uint32_t i = threadIdx.x; i < a.groups; i += kSmall) {
+	if (a.rec_count[i] > a.rec_cap)
+	    flags |= SORA_NOALLOC_RECORDS_FULL;
+	if (a.sq_count[i] > a.sq_cap)
+	    flags |= SORA_NOALLOC_SQUITTERS_FULL;
+    }
+    for (uint32_t i = threadIdx.x; i < a.regions; i += kSmall)
+	if (a.acc_count[i] > a.acc_cap)
+	    flags |= SORA_NOALLOC_FRAMES_FULL;
+    if (flags != 0)
+	atomicOr(&s_flags, flags);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+	const uint64_t total = a.acc_offset[a.regions];
+	flags = s_flags;
+	if (total > a.frames_cap || total > cap_frames)
+	    flags |= SORA_NOALLOC_FRAMES_FULL;
+	if (a.seen_fail != nullptr && *a.seen_fail != 0)
+	    flags |= SORA_NOALLOC_ADDRESSES_FULL;
+	status[0] = total;
+	status[1] = flags;
+    }
+}
+
 __global__ void
 magnitude_kernel(const uint8_t *iq, uint64_t n, int encoding, float *m) {
     uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
@@ -1529,8 +1626,12 @@ sora_launch_fill_u64(uint64_t *dst, uint64_t value, uint64_t n,
 hipError_t
 sora_launch_first_seen(const sora_resolve_args *a, hipStream_t stream) {
     (void) hipGetLastError();
-    hipLaunchKernelGGL(first_seen_kernel, dim3(a->groups), dim3(kSmall), 0,
-	    stream, *a);
+    if (a->seen_keys != nullptr)
+	hipLaunchKernelGGL(first_seen_kernel<true>, dim3(a->groups), dim3(kSmall), 0,
+		stream, *a);
+    else
+	hipLaunchKernelGGL(first_seen_kernel<false>, dim3(a->groups), dim3(kSmall), 0,
+		stream, *a);
     return hipGetLastError();
 }
 
@@ -1586,8 +1687,20 @@ sora_launch_export_first(const sora_resolve_args *a, uint64_t *dst, uint64_t dst
 hipError_t
 sora_launch_filter(const sora_resolve_args *a, hipStream_t stream) {
     (void) hipGetLastError();
-    hipLaunchKernelGGL(filter_kernel, dim3((a->regions + kFilterWaves - 1) / kFilterWaves),
-	    dim3(kSmall), 0, stream, *a);
+    const dim3 grid((a->regions + kFilterWaves - 1) / kFilterWaves);
+    if (a->seen_keys != nullptr)
+	hipLaunchKernelGGL(filter_kernel<true>, grid, dim3(kSmall), 0, stream, *a);
+    else
+	hipLaunchKernelGGL(filter_kernel<false>, grid, dim3(kSmall), 0, stream, *a);
+    return hipGetLastError();
+}
+
+hipError_t
+sora_launch_noalloc_status(const sora_resolve_args *a, uint64_t cap_frames, uint64_t *status,
+	hipStream_t stream) {
+    (void) hipGetLastError();
+    hipLaunchKernelGGL(noalloc_status_kernel, dim3(1), dim3(kSmall), 0, stream, *a,
+	    cap_frames, status);
     return hipGetLastError();
 }
 
