@@ -9,8 +9,10 @@ a host segment the node's ranks share; rank 0 reads the whole list there).
 Two captures are in flight (--inflight): the scan of one overlaps the resolve
 and the host copy of the one before.  At N=1 the workload
 is BASELINE.json configs[1]: a 1-hour 2 MS/s uc8 capture (7.2 G samples,
-14.4 GB) with DF17/DF11 at mixed SNR.  For N>1 every rank holds one such
-1-hour shard of an N-hour capture (weak scaling), 239 halo samples behind it.
+14.4 GB) with DF17/DF11 at mixed SNR.  For N>1 the default is configs[2]: the
+SAME 1-hour capture in N haloed time shards (strong scaling: 900 M owned
+positions + 239 halo samples per rank at N=8); --scaling weak gives every rank
+a 1-hour shard of an N-hour capture instead.
 
     python bench.py --gpus 1 --steps 30 --warmup 5
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
@@ -39,7 +41,11 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--samples", type=float, default=7.2e9,
-                    help="samples per GPU (default: 1 hour at 2 MS/s)")
+                    help="samples of the capture (strong) or per GPU (weak); "
+                         "default: 1 hour at 2 MS/s")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
+                    help="strong (BASELINE.json configs[2]): the one capture split over "
+                         "the ranks; weak: one such capture per rank")
     ap.add_argument("--cpu-samples", type=float, default=120e6,
                     help="bounded sample for the CPU baseline leg (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -89,6 +95,25 @@ def cpu_all_cores(path, n_cpu):
                       f"process each, {dt:.2f} s wall", "frames": frames}
 
 
+def cpu_default_flags(path, n_cpu):
+    """The same reference build with the flags its own configure uses
+    (-std=c99 -g, no optimisation: reference configure:58, :242), on the first
+    half of the window so that the leg stays bounded (about 10 s)."""
+    ref = os.path.join(ROOT, "oracle", "_ref", "ref_sora_adsb")
+    if not os.path.exists(ref):
+        return None
+    n = n_cpu // 2
+    t0 = time.perf_counter()
+    p = subprocess.run(["bash", "-c", f"head -c {2 * n} {path} | {ref} --adsb-decode "
+                        "--adsb-from-raw --adsb-to-bitstring | wc -l"],
+                       capture_output=True, check=True)
+    dt = time.perf_counter() - t0
+    return {"value": round(n / dt / 1e6, 3), "unit": "Msamples/s", "cores": 1,
+            "sample": f"first {n} samples, oracle/_ref/ref_sora_adsb (reference sources, "
+                      f"its own flags: gcc -std=c99 -g), {dt:.1f} s wall",
+            "frames": int(p.stdout)}
+
+
 def cpu_baseline(d_iq, n_cpu, gpu_accepted_in_window):
     """The reference itself (oracle/_ref, built from /root/reference by
     oracle/Makefile) timed on one host core over the first n_cpu samples of the
@@ -110,6 +135,7 @@ def cpu_baseline(d_iq, n_cpu, gpu_accepted_in_window):
             kind = "reference"
             what = "oracle/_ref/ref_sora_adsb_O2 (reference sources, gcc -O2), stdin"
             many = cpu_all_cores(tf.name, n_cpu)
+            plain = cpu_default_flags(tf.name, n_cpu)
         else:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_binding as ob
@@ -118,14 +144,14 @@ def cpu_baseline(d_iq, n_cpu, gpu_accepted_in_window):
             dt = time.perf_counter() - t0
             kind = "port"
             what = "oracle/adsb_oracle.c (gcc -O2)"
-            many = None
+            many = plain = None
     return {
         "value": round(n_cpu / dt / 1e6, 3), "unit": "Msamples/s", "cores": 1,
         "kind": kind,
         "sample": f"first {n_cpu} samples ({n_cpu / 2e6:.0f} s) of the same capture, "
                   f"{what}, {dt:.1f} s wall",
         "frames": frames, "gpu_frames_same_window": gpu_accepted_in_window,
-        "all_cores": many,
+        "all_cores": many, "ref_default_flags": plain,
     }
 
 
@@ -161,17 +187,21 @@ def main():
 
     enc = ENCODING_NAMES[args.encoding]
     bps = BPS[enc]
-    per_gpu = int(args.samples)
-    per_gpu -= per_gpu % 8                                   # shard starts stay 16-byte aligned
-    total = per_gpu * world
-    last = rank == world - 1
-    n_local = per_gpu + (0 if last else sora_amd.HALO)
+    if args.scaling == "strong":
+        from sora_amd.sharded import plan_shards
+        total = int(args.samples)
+        first, per_gpu, n_local = plan_shards(total, world)[rank]   # starts: multiples of 8
+    else:
+        per_gpu = int(args.samples)
+        per_gpu -= per_gpu % 8                               # shard starts stay 16-byte aligned
+        total = per_gpu * world
+        first = rank * per_gpu
+        n_local = per_gpu + (0 if rank == world - 1 else sora_amd.HALO)
 
     # ---- synthetic capture, generated straight into HBM ----
     params = synth.default_params(4 if args.encoding == "sc16" else 2, n_samples=total)
     params.encoding = enc
     frames = synth.make_frames(params)
-    first = rank * per_gpu
     lo = np.searchsorted(frames["position"], max(0, first - 240))
     hi = np.searchsorted(frames["position"], first + n_local)
     d_iq = torch.empty(bps * n_local + 16, dtype=torch.uint8, device=dev)
@@ -179,7 +209,8 @@ def main():
                       first=first)
     torch.cuda.synchronize()
 
-    max_frames = per_gpu // (64 if args.encoding == "sc16" else 1024) + 65536
+    max_frames = max(per_gpu, int(args.samples) // world) // (
+        64 if args.encoding == "sc16" else 1024) + 65536
     collective = world > 1 or args.force_collective
     # `inflight` decoders, each a context on a stream of its own: while one
     # capture's frames are resolved and copied to the host, the next capture's
@@ -294,30 +325,57 @@ def main():
     kernel_ms = float(np.mean(scan_ms))
     # HBM bytes per launch from the PMC passes of this same workload
     # (tools/hbm_traffic.py: FETCH_SIZE x2 + WRITE_SIZE); null if none matches
-    traffic = None
+    traffic = traffic_source = None
     try:
         with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as fh:
             entry = json.load(fh).get(f"{kernel_name}:{args.encoding}:{n_local * bps}")
         if entry:
             traffic = round(entry["traffic_bytes"])
+            traffic_source = ("profiles/hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / "
+                              "WRITE_SIZE passes over this workload (tools/hbm_traffic.py), "
+                              "committed; not re-measured in this run")
     except (OSError, ValueError):
         pass
     achieved = n_local * bps / (kernel_ms * 1e-3) / 1e9
+    ms_per_step = dt / args.steps * 1e3
+    # the whole step against the same roofline: algorithmic bytes of all ranks
+    # over the step time, per GPU
+    step_gbs = total * bps / world / (ms_per_step * 1e-3) / 1e9
 
+    hour = args.encoding == "uc8" and int(args.samples) == 7200000000
+    if hour and world == 1:
+        workload = ("configs[1]: 1-hour synthetic 2 MS/s uc8 capture (DF17/DF11 at mixed "
+                    "SNR), scan + resolve + frame list to host")
+    elif hour and args.scaling == "strong":
+        workload = (f"configs[2]: the same 1-hour synthetic 2 MS/s uc8 capture in {world} "
+                    "haloed time shards, scan + squitter exchange + resolve + frame lists "
+                    "to host")
+    elif hour:
+        workload = (f"side measurement (weak scaling): a 1-hour uc8 shard per GPU of a "
+                    f"{world}-hour capture")
+    else:
+        workload = (f"side measurement: {total} samples of {args.encoding} over {world} "
+                    "GPU(s), scan + resolve + frame list to host")
     line = {
         "metric": f"Msamples/s ADS-B decoded (2MS/s {args.encoding} IQ)",
         "value": round(total * args.steps / dt / 1e6, 1),
         "unit": "Msamples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(dt / args.steps * 1e3, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True, "scaling": args.scaling,
+        "vs_baseline": None,
         "dtype": "f32" if args.encoding == "sc16" else "u8", "data": "synthetic",
         "config": {
-            "workload": ("configs[1]: 1-hour synthetic 2 MS/s uc8 capture per GPU "
-                         "(DF17/DF11 at mixed SNR), scan + resolve + frame list to host"
-                         if args.encoding == "uc8" and per_gpu == 7200000000 else
-                         f"side measurement: {per_gpu} samples of {args.encoding} per GPU, "
-                         "scan + resolve + frame list to host"),
+            "workload": workload,
+            "parallelism": "1 GPU" if world == 1 else
+                           f"{world} haloed time shards, one rank per GPU ({args.scaling})",
+            "exchange": None if not collective else
+                        "squitter records: one 64 KB all-gather over RCCL/xGMI per step",
+            "gather": None if not collective else
+                      ("frame lists to a host segment shared by the node's ranks, every rank "
+                       "over its own PCIe link (--gather shm)" if decs[0].gather == "shm" else
+                       "frame lists gathered to rank 0 with RCCL over xGMI (--gather collective)"),
+            "samples_total": total,
             "samples_per_gpu": per_gpu, "bytes_per_gpu": bps * n_local,
             "injected_frames": int(len(frames)), "frames_out": int(n_frames),
             "candidates_rank0": int(counts["candidates"]),
@@ -327,6 +385,10 @@ def main():
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "traffic_source": traffic_source,
+            "step_frac": round(step_gbs / HBM_PEAK_GBS, 4),
+            "step_frac_is": "algorithmic bytes per GPU / ms_per_step / peak: the whole "
+                            "step (scan + resolve + frames to host), not the scan kernel alone",
             "kernel": f"{kernel_name} ({args.encoding})",
             "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes": n_local * bps,
         },

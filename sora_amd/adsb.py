@@ -150,20 +150,32 @@ class AdsbContext:
     def stream(self, source, encoding, block_samples):
         """Streaming ingest (sora_adsb_stream_*): `source` is a bytes-like object
         or a binary file object; yields one FRAME_DTYPE array per block."""
+        failure = []        # ctypes swallows an exception raised inside a callback:
+                            # keep it, end the stream, raise it afterwards
+
         if hasattr(source, "readinto"):
-            def read(_user, dst, nbytes):
+            def read_some(dst, nbytes):
                 buf = (C.c_char * nbytes).from_address(dst)
                 return source.readinto(buf) or 0
         else:
             view = memoryview(source).cast("B")
             at = [0]
 
-            def read(_user, dst, nbytes):
+            def read_some(dst, nbytes):
                 k = min(nbytes, len(view) - at[0])
                 if k > 0:
                     C.memmove(dst, (C.c_char * k).from_buffer_copy(view[at[0]:at[0] + k]), k)
                 at[0] += k
                 return k
+
+        def read(_user, dst, nbytes):
+            if failure:
+                return 0
+            try:
+                return read_some(dst, nbytes)
+            except BaseException as e:          # noqa: BLE001 -- re-raised below
+                failure.append(e)
+                return 0
         cb = _lib.READ_FN(read)
         check(lib().sora_adsb_stream_begin(self._h, int(encoding), int(block_samples),
                                            cb, None), self._h)
@@ -171,6 +183,8 @@ class AdsbContext:
             while True:
                 ptr, n = C.c_void_p(), C.c_size_t()
                 rc = lib().sora_adsb_stream_next(self._h, C.byref(ptr), C.byref(n))
+                if failure:
+                    raise failure[0]    # the source failed: not the end of the stream
                 if rc == _lib.END:
                     break
                 check(rc, self._h)

@@ -25,7 +25,7 @@ struct sora_adsb_ctx {
 
     sora_adsb_config cfg;
     uint32_t max_groups;	/* workgroups the scan kernel may use */
-    uint32_t scan_variant;	/* 8-bit scan kernel: 0 M through LDS, 1/2 M in registers (256/512 threads) */
+    uint32_t scan_variant;	/* 8-bit scan kernel: 1 magnitudes in registers (default), 0 through LDS */
     uint32_t scan_rounds, scan_min_tiles;	/* see sora_adsb_create() */
     uint32_t max_regions;	/* accepted regions (sora_filter_max_regions) */
     uint32_t cus;
@@ -335,7 +335,7 @@ sora_adsb_create(sora_adsb_ctx **out, int device, const sora_adsb_config *cfg) {
      * least kMinTiles tiles (the CRC tables are loaded into LDS once per range).
      * SORA_ADSB_SCAN_ROUNDS / SORA_ADSB_SCAN_MIN_TILES override both (tuning and
      * tests). */
-    ctx->scan_variant = env_number("SORA_ADSB_SCAN_VARIANT", 1, 0, 2);
+    ctx->scan_variant = env_number("SORA_ADSB_SCAN_VARIANT", 1, 0, 1);
     ctx->scan_rounds = env_number("SORA_ADSB_SCAN_ROUNDS", kScanRounds, 1, 64);
     ctx->scan_min_tiles = env_number("SORA_ADSB_SCAN_MIN_TILES", kMinTiles, 1, 1 << 20);
     ctx->max_groups = ctx->cus * 8 * ctx->scan_rounds;
@@ -1066,8 +1066,7 @@ sora_adsb_scan_kernel_name(const sora_adsb_ctx *ctx, int encoding) {
 	return "";
     if (encoding == SORA_ENC_SC16)
 	return "adsb_scan_kernel<true>";
-    return ctx->scan_variant == 1? "adsb_scan_direct_kernel<256>" :
-	    ctx->scan_variant == 2? "adsb_scan_direct_kernel<512>" : "adsb_scan_kernel<false>";
+    return ctx->scan_variant == 1? "adsb_scan_direct_kernel<256>" : "adsb_scan_kernel<false>";
 }
 
 extern "C" int

@@ -2,25 +2,36 @@
  * adsb_kernels.hip -- gfx950 (MI355X) kernels of the ADS-B receive chain.
  *
  * Replaces the per-sample loop of reference src/ads-b/plane-iq.c:141-194 and
- * the validation head of src/ads-b/plane.c:457-484.  Design notes live in
- * DESIGN.md; the per-lane arithmetic is in adsb_tile.h.
+ * the validation head of src/ads-b/plane.c:457-484.  Design notes and
+ * measurements live in DESIGN.md; the per-lane arithmetic is in adsb_tile.h.
  *
- * scan kernel, one 256-thread workgroup per 16128-position tile pass:
- *   phase 1  16-byte coalesced buffer loads of raw IQ (8 samples per lane and
- *            load), I^2+Q^2 by v_dot4_i32_i8, two 16-bit magnitudes per dword
- *            into LDS (lane-run layout, 36-dword stride)
- *   phase 2  every lane walks 32 pairs (64 positions) out of LDS and shifts
- *            six compare results per pair into MSB-first bit words: NU (the
- *            PPM slicer bit of EVERY position), D, C, split by parity
- *   phase 3  predicate = a few word-wide ANDs of shifted words; hits are
- *            compacted in position order into an LDS queue (block scan)
- *   phase 4  one lane per candidate: 112 message bits are 112 consecutive
- *            elements of an NU array (funnel shifts), CRC-24 by byte table,
- *            DF classification; records leave in position order through an
- *            ordered block compaction, into this workgroup's private region:
- *            no global atomics anywhere
- * A workgroup walks a contiguous range of tiles, so the concatenation of the
- * regions is sorted by position by construction.
+ * Scan kernels (one launch per chunk; a workgroup walks a contiguous range of
+ * tiles and writes its candidate records, in position order, into a region of
+ * its own, so the concatenation of the regions is sorted by construction and
+ * there is no global atomic, compaction or sort):
+ *   adsb_scan_direct_kernel<256>   uc8 / sc8, the default.  A lane loads its own
+ *       64 bytes (32 positions), keeps the 16-bit magnitudes in registers,
+ *       takes the next lane's first pairs over DPP; only the NU bit arrays, the
+ *       hit prefix and the hit queue go through LDS: two barriers per tile.
+ *   adsb_scan_kernel<true>         sc16: 32-bit magnitudes staged through LDS.
+ *   adsb_scan_kernel<false>        uc8 / sc8 with the magnitudes staged through
+ *       LDS (SORA_ADSB_SCAN_VARIANT=0): the independent second implementation
+ *       the variant tests compare the default against.
+ *   phases of every one of them:
+ *     1  16-byte coalesced buffer loads of raw IQ, I^2+Q^2 by v_dot4_i32_i8
+ *        (v_dot2_i32_i16 + v_cvt for sc16)
+ *     2  compare bits of a lane's 32 positions with packed 16-bit VALU: NU (the
+ *        PPM slicer bit of EVERY position), D, C, split by parity
+ *     3  predicate = a few word-wide ANDs of shifted words; hits are counted,
+ *        prefix-summed (DPP scan + one LDS atomic per wave) and queued in
+ *        position order
+ *     4  one lane per candidate: 112 message bits are 112 consecutive elements
+ *        of an NU array (funnel shifts), CRC-24 by eleven sliced table lookups,
+ *        DF classification, a 6-byte record at the slot of its queue index
+ * Resolve kernels: first_seen / add_known (known addresses), filter (the one
+ * stateful rule as first_seen[A] < P), scan_counts + flatten (offsets, flat
+ * list), finalize (re-slices accepted frames from the samples: bits, CRC,
+ * amplitude).
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -108,15 +119,6 @@ rank_in_mask(unsigned long long mask) {
  * The two s_nop cover the VALU-write -> DPP-read hazard of gfx9. */
 __device__ __forceinline__ uint32_t
 wave_inclusive_scan(uint32_t v) {
-#ifdef SORA_NO_ASM_SCAN
-    const uint32_t lane = threadIdx.x & 63;
-    for (int d = 1; d < 64; d <<= 1) {
-	uint32_t o = __shfl_up(v, d, 64);
-	if (lane >= (uint32_t) d)
-	    v += o;
-    }
-    return v;
-#endif
     asm("s_nop 1\n\t"
 	"v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
 	"s_nop 1\n\t"
@@ -626,9 +628,6 @@ adsb_scan_direct_kernel(sora_scan_args a) {
 	for (int r = 0; r < 4; r++)
 	    v[r] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, g * 64, r * 16, 0);
     };
-#ifdef SORA_DIRECT_PREFETCH
-    u32x4 v[4];
-#endif
 
     for (uint64_t tile = tile_begin; tile < tile_end; tile++) {
 	const uint64_t tile_start = tile * kTilePos;
@@ -643,23 +642,15 @@ adsb_scan_direct_kernel(sora_scan_args a) {
 	/* ---- phase 1: this lane's 64 bytes, magnitudes in registers ---- */
 	uint32_t P[SORA_LANE_PAIRS + 4];
 	{
-#ifdef SORA_DIRECT_PREFETCH
-	    /* the loads were issued a tile ahead */
-	    if (tile == tile_begin)
-		load_run(v, tile, g);
-#else
+	    /* (issued a tile ahead instead, the 16 live registers of the loads in
+	     * flight spill at 7 waves per SIMD: measured slower) */
 	    u32x4 v[4];
 	    load_run(v, tile, g);
-#endif
 #pragma unroll
 	    for (int r = 0; r < 4; r++) {
 		const uint32_t raw[4] = {v[r][0], v[r][1], v[r][2], v[r][3]};
 		sora_mag2_pack8x4(raw, flip, &P[4 * r]);
 	    }
-#ifdef SORA_DIRECT_PREFETCH
-	    if (tile + 1 < tile_end)
-		load_run(v, tile + 1, g);
-#endif
 #pragma unroll
 	    for (int i = 0; i < 4; i++)
 		P[16 + i] = next_lane(P[i]);
@@ -1559,8 +1550,6 @@ uint32_t
 sora_scan_tile_pos(int encoding, int variant) {
     if (encoding != SORA_ENC_SC16 && variant == 1)
 	return direct_geom<256>::tile_pos;
-    if (encoding != SORA_ENC_SC16 && variant == 2)
-	return direct_geom<512>::tile_pos;
     return encoding == SORA_ENC_SC16? SORA16_TILE_POS : SORA_TILE_POS;
 }
 
@@ -1574,8 +1563,6 @@ uint32_t
 sora_scan_groups_per_cu(int encoding, int variant) {
     if (encoding != SORA_ENC_SC16 && variant == 1)
 	return SORA_DIRECT_WAVES;	/* 256 threads: as many workgroups as waves per SIMD */
-    if (encoding != SORA_ENC_SC16 && variant == 2)
-	return 3;
     /* workgroups of one CU: bounded by LDS (53 KB and 39 KB per workgroup) */
 #ifdef SORA_GROUPS_PER_CU
     return encoding == SORA_ENC_SC16? 4 : SORA_GROUPS_PER_CU;
@@ -1586,14 +1573,10 @@ sora_scan_groups_per_cu(int encoding, int variant) {
 
 hipError_t
 sora_launch_scan(const sora_scan_args *a, uint32_t groups, int variant, hipStream_t stream) {
-    if (a->encoding != SORA_ENC_SC16 && (variant == 1 || variant == 2)) {
+    if (a->encoding != SORA_ENC_SC16 && variant == 1) {
 	(void) hipGetLastError();
-	if (variant == 1)
-	    hipLaunchKernelGGL(adsb_scan_direct_kernel<256>, dim3(groups), dim3(256), 0,
-		    stream, *a);
-	else
-	    hipLaunchKernelGGL(adsb_scan_direct_kernel<512>, dim3(groups), dim3(512), 0,
-		    stream, *a);
+	hipLaunchKernelGGL(adsb_scan_direct_kernel<256>, dim3(groups), dim3(256), 0,
+		stream, *a);
 	return hipGetLastError();
     }
     switch (a->encoding) {
