@@ -13,6 +13,10 @@
  *       64 bytes (32 positions), keeps the 16-bit magnitudes in registers,
  *       takes the next lane's first pairs over DPP; only the NU bit arrays, the
  *       hit prefix and the hit queue go through LDS: two barriers per tile.
+ *       The next tile's samples are in flight while a tile is worked on; every
+ *       pass of the tile loop issues the same vector memory operations (four
+ *       loads, two stores) so that the wait for the samples is a fixed
+ *       `all but the N youngest' that leaves the record stores out.
  *   adsb_scan_kernel<true>         sc16: 32-bit magnitudes staged through LDS.
  *   adsb_scan_kernel<false>        uc8 / sc8 with the magnitudes staged through
  *       LDS (SORA_ADSB_SCAN_VARIANT=0): the independent second implementation
@@ -570,9 +574,16 @@ next_lane(uint32_t v) {
     return (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x130, 0xf, 0xf, true);
 }
 
+/*
+ * Waves per SIMD (= workgroups per CU) of the direct kernel: the sixteen
+ * registers that hold the next tile's samples while this tile is worked on
+ * (see the tile loop) take the kernel from 71 to about 90 VGPRs.
+ */
 #ifndef SORA_DIRECT_WAVES
-#define SORA_DIRECT_WAVES 7
+#define SORA_DIRECT_WAVES 5
 #endif
+constexpr int kSqLds = 128;		/* clean squitters a workgroup keeps in LDS */
+
 template <int kThreads>
 __global__ void __launch_bounds__(kThreads, SORA_DIRECT_WAVES)
 adsb_scan_direct_kernel(sora_scan_args a) {
@@ -590,6 +601,11 @@ adsb_scan_direct_kernel(sora_scan_args a) {
     __shared__ uint16_t s_queue[kQueueMax];
     __shared__ uint32_t s_cum[2][kWaves + 1];	/* by tile parity, see below */
     __shared__ uint32_t s_sq_total;
+    /* the workgroup's clean squitters (about sixty per range of the 1-hour
+     * capture): kept here and written out as the workgroup ends, so that the
+     * tile loop issues no store that only some tiles have (see the tile loop);
+     * those beyond kSqLds go straight to the global list */
+    __shared__ uint64_t s_sq[kSqLds];
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63, wave = tid >> 6;
@@ -598,11 +614,18 @@ adsb_scan_direct_kernel(sora_scan_args a) {
     const uint64_t tile_begin = a.n_tiles * group / groups;
     const uint64_t tile_end = a.n_tiles * (group + 1) / groups;
 
-    uint32_t *key_out = a.key + (uint64_t) group * a.rec_cap;
-    uint16_t *tail_out = a.tail + (uint64_t) group * a.rec_cap;
     uint64_t *sq_out = a.sq + (uint64_t) group * a.sq_cap;
     uint32_t n_rec = 0;
     uint32_t st_cand = 0, st_sq = 0, st_dirty = 0, st_fixed = 0;
+
+    /* The record region of this workgroup as two buffers: a store beyond the
+     * region (a full region, or a lane that has no record: offset ~0) is
+     * dropped by the bounds check -- no branch around the stores. */
+    const uint64_t rec_bytes = (uint64_t) a.rec_cap * 4;
+    auto rsrc_key = __builtin_amdgcn_make_buffer_rsrc(a.key + (uint64_t) group * a.rec_cap, 0,
+	    rec_bytes > 0xfffffffcull? 0xfffffffcu : (uint32_t) rec_bytes, 0x00020000);
+    auto rsrc_tail = __builtin_amdgcn_make_buffer_rsrc(a.tail + (uint64_t) group * a.rec_cap, 0,
+	    rec_bytes / 2 > 0xfffffffeull? 0xfffffffeu : (uint32_t) (rec_bytes / 2), 0x00020000);
 
     {
 	const u32x4 *src = reinterpret_cast<const u32x4 *>(g_crc_slices.w);
@@ -615,10 +638,12 @@ adsb_scan_direct_kernel(sora_scan_args a) {
     }
     __syncthreads();
 
-    /* the 64 bytes of lane run g of a tile: four 16-byte loads */
-    auto load_run = [&](u32x4 *v, uint64_t tile_no, uint32_t g) {
-	const uint64_t start = tile_no * kTilePos;
-	uint64_t left = (a.n_samples - start) * 2;
+    /* the 64 bytes of lane run g of a tile: four 16-byte loads.  `live` false:
+     * the same four instructions on an empty buffer (they fetch nothing and
+     * return zeros) -- see the tile loop for why they are still issued */
+    auto load_run = [&](u32x4 *v, uint64_t tile_no, uint32_t g, bool live) {
+	const uint64_t start = live? tile_no * kTilePos : 0;
+	uint64_t left = live? (a.n_samples - start) * 2 : 0;
 	left = (left + 3) & ~3ull;
 	const uint32_t span = left < (uint64_t) D::tile_bytes?
 		(uint32_t) left : (uint32_t) D::tile_bytes;
@@ -628,6 +653,39 @@ adsb_scan_direct_kernel(sora_scan_args a) {
 	for (int r = 0; r < 4; r++)
 	    v[r] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, g * 64, r * 16, 0);
     };
+    /* a record's key and tail at slot idx of the region; idx = ~0: none */
+    auto store_record = [&](uint32_t idx, uint32_t key, uint32_t tail) {
+	const uint32_t none = idx == 0xffffffffu;
+	__builtin_amdgcn_raw_buffer_store_b32(key, rsrc_key, none? 0xffffffffu : idx * 4, 0, 0);
+	__builtin_amdgcn_raw_buffer_store_b16((uint16_t) tail, rsrc_tail,
+		none? 0xffffffffu : idx * 2, 0, 0);
+    };
+
+    /*
+     * The tile loop is software-pipelined over the memory system: the samples
+     * of tile t + 1 are requested as soon as the registers that held tile t's
+     * are free (behind phase 1) and arrive while phases 2-4 of tile t run.
+     * (Without this a wave waits for HBM at the top of every tile and is
+     * parked for half of its life, SQ_WAIT_ANY 53 % of SQ_WAVE_CYCLES; with it
+     * the wait is 0.4 % of the tile.  Seven such waves per SIMD and five of
+     * these take the same time on the 1-hour capture -- the kernel is bound
+     * by VALU issue either way, DESIGN.md 5.1 -- but a short shard no longer
+     * pays the latency.)  Vector memory operations retire in issue order, and the wait
+     * at the top of the loop is `all but the N youngest', N fixed at compile
+     * time: for that wait not to include the record stores of phase 4 -- which
+     * come AFTER the loads -- every pass through the loop must issue the SAME
+     * operations: four loads and two stores, whatever the tile holds.  Hence
+     * loads on an empty buffer behind the last tile, stores with an
+     * out-of-range offset for lanes without a record, the squitter list in
+     * LDS, and two dropped stores in front of the loop so that the first pass
+     * finds what every other pass finds.  (A tile with more than kThreads
+     * candidates takes extra passes with stores of their own: more operations
+     * behind the loads only make the wait conservative.)
+     */
+    u32x4 v[4];
+    load_run(v, tile_begin, 63 * wave + lane, tile_begin < tile_end);
+    store_record(0xffffffffu, 0, 0);
+    STAMP_DECL;
 
     for (uint64_t tile = tile_begin; tile < tile_end; tile++) {
 	const uint64_t tile_start = tile * kTilePos;
@@ -635,33 +693,45 @@ adsb_scan_direct_kernel(sora_scan_args a) {
 	 * sora_adsb_scan checks) */
 	const uint32_t region_off = (uint32_t) (tile - tile_begin) * (uint32_t) kTilePos;
 	const uint32_t par = (uint32_t) (tile - tile_begin) & 1;
-	/* lane run of this lane, opaque per tile (see adsb_scan_kernel) */
-	uint32_t g = 63 * wave + lane;
-	asm volatile("" : "+v"(g));
+	/* The thread index, made opaque once per tile (see adsb_scan_kernel): the
+	 * LDS addresses derived from it are then formed inside the loop, next to
+	 * their use; hoisted out of it they are a dozen VGPRs of loop invariants,
+	 * and at this kernel's register budget a spilled invariant is reloaded
+	 * behind an s_waitcnt vmcnt(0) that also waits for the next tile's loads.
+	 * t: thread, l: lane, w: wave (scalar), g: lane run of this lane. */
+	uint32_t t = tid;
+	asm volatile("" : "+v"(t));
+	const uint32_t l = t & 63;
+	const uint32_t w = (uint32_t) __builtin_amdgcn_readfirstlane((int) (t >> 6));
+	const uint32_t g = 63 * w + l;
 
 	/* ---- phase 1: this lane's 64 bytes, magnitudes in registers ---- */
 	uint32_t P[SORA_LANE_PAIRS + 4];
+	STAMP_BEGIN();
+#ifdef SORA_SCAN_STAMPS
+	asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+#endif
+	STAMP(0);			/* what is left of the HBM latency of the tile's loads */
 	{
-	    /* (issued a tile ahead instead, the 16 live registers of the loads in
-	     * flight spill at 7 waves per SIMD: measured slower) */
-	    u32x4 v[4];
-	    load_run(v, tile, g);
 #pragma unroll
 	    for (int r = 0; r < 4; r++) {
 		const uint32_t raw[4] = {v[r][0], v[r][1], v[r][2], v[r][3]};
 		sora_mag2_pack8x4(raw, flip, &P[4 * r]);
 	    }
+	    load_run(v, tile + 1, g, tile + 1 < tile_end);	/* in flight through phases 2-4 */
 #pragma unroll
 	    for (int i = 0; i < 4; i++)
 		P[16 + i] = next_lane(P[i]);
 	}
 
+	STAMP(1);			/* magnitudes, next tile's loads issued */
 	/* ---- phase 2: compare bits of this lane's 32 positions ---- */
 	uint32_t up, down, cc;
 	sora_lane_compare(P, &up, &down, &cc);
 	const uint32_t nu = ~up;
+	STAMP(2);			/* compares */
 	uint16_t *const s_nue = s_bits[par][0], *const s_nuo = s_bits[par][1];
-	if (lane != 63) {		/* the halo lane's run belongs to the next wave */
+	if (l != 63) {		/* the halo lane's run belongs to the next wave */
 	    s_nue[g ^ 1] = (uint16_t) (nu & 0xffffu);
 	    s_nuo[g ^ 1] = (uint16_t) (nu >> 16);
 	}
@@ -687,23 +757,25 @@ adsb_scan_direct_kernel(sora_scan_args a) {
 		pe &= ve;
 		po &= vo;
 	    }
-	    if (lane == 63)
+	    if (l == 63)
 		pe = po = 0;
 	}
 	const uint32_t cnt = __popc(pe | po);
 	const uint32_t incl = wave_inclusive_scan(cnt);
 	{
 	    const uint32_t wave_hits = (uint32_t) __builtin_amdgcn_readlane((int) incl, 63);
-	    if (lane > wave && lane <= (uint32_t) kWaves)
-		atomicAdd(&s_cum[par][lane], wave_hits);
+	    if (l > w && l <= (uint32_t) kWaves)
+		atomicAdd(&s_cum[par][l], wave_hits);
 	}
+	STAMP(3);			/* predicate, hit count, wave prefix */
 	lds_barrier();			/* A: every wave is done with the previous tile */
+	STAMP(4);			/* barrier A */
 	const uint32_t total = s_cum[par][kWaves];
-	uint32_t off = s_cum[par][wave] + incl - cnt;
+	uint32_t off = s_cum[par][w] + incl - cnt;
 	/* the other parity's prefix is used next by the following tile's atomics,
 	 * which no wave reaches before barrier B */
-	if (tid <= (uint32_t) kWaves)
-	    s_cum[par ^ 1][tid] = 0;
+	if (t <= (uint32_t) kWaves)
+	    s_cum[par ^ 1][t] = 0;
 	{
 	    uint32_t both = pe | po;
 	    while (both != 0) {
@@ -713,63 +785,80 @@ adsb_scan_direct_kernel(sora_scan_args a) {
 		both &= ~(0x80000000u >> b);
 	    }
 	}
+	STAMP(5);			/* queue */
 	lds_barrier();			/* B */
+	STAMP(6);			/* barrier B */
 
 	/* ---- phase 4: one lane per candidate (as adsb_scan_kernel) ---- */
 	const uint32_t *w_nue = reinterpret_cast<const uint32_t *>(s_nue);
 	const uint32_t *w_nuo = reinterpret_cast<const uint32_t *>(s_nuo);
 	st_cand += total;
-	for (uint32_t base = 0; base < total; base += kThreads) {
-	    const uint32_t i = base + tid;
+	/* candidate i of the tile: its record (slot n_rec + i) and statistics */
+	auto candidate = [&](uint32_t i, uint32_t *key, uint32_t *tail) {
+	    uint32_t q = s_queue[i];
+	    const uint32_t *words = (q & 1)? w_nuo : w_nue;
+	    uint32_t bits[4];
+	    sora_candidate c;
 
+	    sora_extract_bits(words, (q >> 1) + 8, bits);
+	    sora_classify(bits, s_tab, &c);
+	    uint32_t kind = !c.squitter? (uint32_t) SORA_REC_KIND_REPLY :
+		    c.syndrome == 0? (uint32_t) SORA_REC_KIND_SQUITTER :
+		    (uint32_t) SORA_REC_KIND_DIRTY;
+	    uint32_t payload = kind == SORA_REC_KIND_DIRTY? c.syndrome : c.address;
+	    if (a.correct && kind == SORA_REC_KIND_DIRTY) {
+		const int b = sora_fix_bit(c.syndrome, c.is_long? 112 : 56,
+			s_tab + SORA_CRC_TABLE_WORDS);
+		if (b >= 0) {
+		    kind = (uint32_t) SORA_REC_KIND_CORRECTED;
+		    payload = c.address;
+		    if (b >= 8 && b < 32)
+			payload ^= 1u << (31 - b);
+		}
+	    }
+	    const uint32_t rpos = region_off + q;
+	    *key = payload | (kind << 24) | ((rpos >> 16) << 26);
+	    *tail = rpos;
+	    if (kind == SORA_REC_KIND_SQUITTER || kind == SORA_REC_KIND_CORRECTED) {
+		const uint32_t k = atomicAdd(&s_sq_total, 1u);
+		const uint64_t r = sora_rec_make(kind, tile_start + q, payload);
+		if (k < (uint32_t) kSqLds)
+		    s_sq[k] = r;
+		else if (k < a.sq_cap)
+		    sq_out[k] = r;
+	    }
+	    st_sq += (uint32_t) __popcll(__ballot(kind == SORA_REC_KIND_SQUITTER));
+	    st_dirty += (uint32_t) __popcll(__ballot(kind == SORA_REC_KIND_DIRTY));
+	    if (a.correct)
+		st_fixed += (uint32_t) __popcll(__ballot(kind == SORA_REC_KIND_CORRECTED));
+	};
+	/* the rare passes first (a tile with more than kThreads candidates), the
+	 * pass every tile has last: its two stores are the loop's youngest */
+	for (uint32_t base = kThreads; base < total; base += kThreads) {
+	    const uint32_t i = base + t;
 	    if (i < total) {
-		uint32_t q = s_queue[i];
-		const uint32_t *words = (q & 1)? w_nuo : w_nue;
-		uint32_t bits[4];
-		sora_candidate c;
-
-		sora_extract_bits(words, (q >> 1) + 8, bits);
-		sora_classify(bits, s_tab, &c);
-		uint32_t kind = !c.squitter? (uint32_t) SORA_REC_KIND_REPLY :
-			c.syndrome == 0? (uint32_t) SORA_REC_KIND_SQUITTER :
-			(uint32_t) SORA_REC_KIND_DIRTY;
-		uint32_t payload = kind == SORA_REC_KIND_DIRTY? c.syndrome : c.address;
-		if (a.correct && kind == SORA_REC_KIND_DIRTY) {
-		    const int b = sora_fix_bit(c.syndrome, c.is_long? 112 : 56,
-			    s_tab + SORA_CRC_TABLE_WORDS);
-		    if (b >= 0) {
-			kind = (uint32_t) SORA_REC_KIND_CORRECTED;
-			payload = c.address;
-			if (b >= 8 && b < 32)
-			    payload ^= 1u << (31 - b);
-		    }
-		}
-		const uint32_t rpos = region_off + q;
-		const uint32_t idx = n_rec + i;
-		if (idx < a.rec_cap) {
-		    key_out[idx] = payload | (kind << 24) | ((rpos >> 16) << 26);
-		    tail_out[idx] = (uint16_t) rpos;
-		}
-		if (kind == SORA_REC_KIND_SQUITTER || kind == SORA_REC_KIND_CORRECTED) {
-		    const uint32_t k = atomicAdd(&s_sq_total, 1u);
-		    if (k < a.sq_cap)
-			sq_out[k] = sora_rec_make(kind, tile_start + q, payload);
-		}
-		st_sq += (uint32_t) __popcll(__ballot(kind == SORA_REC_KIND_SQUITTER));
-		st_dirty += (uint32_t) __popcll(__ballot(kind == SORA_REC_KIND_DIRTY));
-		if (a.correct)
-		    st_fixed += (uint32_t) __popcll(__ballot(kind == SORA_REC_KIND_CORRECTED));
+		uint32_t key, tail;
+		candidate(i, &key, &tail);
+		store_record(n_rec + i, key, tail);
 	    }
 	}
+	{
+	    uint32_t key = 0, tail = 0;
+	    if (t < total)
+		candidate(t, &key, &tail);
+	    store_record(t < total? n_rec + t : 0xffffffffu, key, tail);
+	}
 	n_rec += total;
+	STAMP(7);			/* candidates */
 	/* the next tile writes the other parity's NU arrays and prefix; its queue
 	 * writes come behind its barrier A */
     }
 
     lds_barrier();			/* the last tile's squitter appends */
+    const uint32_t n_sq = s_sq_total;
     if (tid == 0) {
 	a.rec_count[group] = n_rec;
-	a.sq_count[group] = s_sq_total;
+	a.sq_count[group] = n_sq;
     }
     {
 	__shared__ uint32_t s_stat[kWaves][3];
@@ -792,9 +881,30 @@ adsb_scan_direct_kernel(sora_scan_args a) {
 	    st[SORA_STAT_DIRTY] = t2;
 	    st[SORA_STAT_REPLIES] = st_cand - t1 - t2 - t3;
 	    st[SORA_STAT_CORRECTED] = t3;
+#ifdef SORA_SCAN_STAMPS
+	    for (int i = 0; i < 8; i++)
+		st[SORA_STAT_WORDS_BASE + i] = st_t[i];
+#endif
 	}
     }
-    merge_squitter_list(a, sq_out, s_sq_total, tid, kThreads);
+    /* the squitter list: out of LDS into the workgroup's global list (export,
+     * first_seen_kernel), and -- first_seen_kernel's work, hidden behind the
+     * other workgroups of the CU -- into the first-seen table */
+    {
+	const uint32_t n = n_sq < a.sq_cap? n_sq : a.sq_cap;
+	for (uint32_t i = tid; i < n; i += kThreads) {
+	    uint64_t r;
+	    if (i < (uint32_t) kSqLds) {
+		r = s_sq[i];
+		sq_out[i] = r;
+	    } else {
+		r = __hip_atomic_load(&sq_out[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	    }
+	    if (a.first_seen != nullptr)
+		note_known(a.first_seen, a.known_bits, sora_rec_addr(r),
+			a.base_position + sora_rec_pos(r));
+	}
+    }
 }
 
 /* ------------------------------------------------------- small kernels -- */
