@@ -60,6 +60,10 @@ def parse_args():
     ap.add_argument("--gather", choices=("shm", "collective"), default="shm",
                     help="N>1: frame lists to rank 0 through a shared host segment "
                          "(every rank over its own PCIe link) or by an RCCL gather")
+    ap.add_argument("--frames", choices=("wire", "full"), default="wire",
+                    help="frame list as 28-byte wire frames (SORA_OPT_WIRE_FRAMES: the same "
+                         "information, unpacked on the host on demand) or as 48-byte "
+                         "struct sora_adsb_frame")
     ap.add_argument("--overlap", action="store_true",
                     help="experiment: do not order the kernels of different captures "
                          "by events (a scan may share the GPU with a resolve)")
@@ -221,7 +225,8 @@ def main():
     for _ in range(max(1, args.inflight)):
         st = torch.cuda.Stream(device=dev)
         ctx = AdsbContext(n_local, device=local, max_squitters=max_frames,
-                          max_frames=max_frames, stream=st.cuda_stream)
+                          max_frames=max_frames, stream=st.cuda_stream,
+                          wire_frames=args.frames == "wire")
         streams.append(st)                           # ~3x the injected frame rate
         ctxs.append(ctx)
         if collective:
@@ -380,6 +385,7 @@ def main():
             "injected_frames": int(len(frames)), "frames_out": int(n_frames),
             "candidates_rank0": int(counts["candidates"]),
             "captures_in_flight": len(decs),
+            "frame_bytes": int(ctx.frame_dtype.itemsize),
             "host_ms_per_step": {k: round(v / args.steps * 1e3, 3) for k, v in phase_s.items()},
         },
         "roofline": {
@@ -397,7 +403,8 @@ def main():
     if (rank == 0 and world == 1 and not args.no_cpu and args.cpu_samples > 0
             and args.encoding == "uc8"):          # the reference reads uc8 only
         n_cpu = min(int(args.cpu_samples), per_gpu)
-        pos = decs[(args.steps - 1) % len(decs)].frames()["position"]
+        last = decs[(args.steps - 1) % len(decs)].frames()
+        pos = (sora_amd.unpack_frames(last, enc) if args.frames == "wire" else last)["position"]
         in_window = int(np.count_nonzero(pos < n_cpu - 239))
         line["cpu_baseline"] = cpu_baseline(d_iq, n_cpu, in_window)
     else:

@@ -95,6 +95,19 @@ extern "C" {
  * they have merged a truncated list, a local re-run cannot repair that.
  */
 #define SORA_OPT_FIXED_LISTS		0x02
+/*
+ * The frame list leaves the device as 28-byte struct sora_adsb_wire_frame
+ * instead of 48-byte struct sora_adsb_frame: with dense traffic (BASELINE.json
+ * configs[3]: 6 M frames per 14.4 GB) the copy of the frame list over PCIe is
+ * what a step waits for.  Nothing is lost: DF, syndrome and address are
+ * functions of the bits, the amplitude travels as the exact integer it is a
+ * multiple of; sora_adsb_unpack_frames() rebuilds the 48-byte frames on the
+ * host, whenever and for whichever frames the caller wants them.  A context
+ * with this option hands out frames through sora_adsb_collect_wire[_device]
+ * only (sora_adsb_collect, _collect_device and the sora_adsb_stream_* calls
+ * return SORA_ERR_STATE).
+ */
+#define SORA_OPT_WIRE_FRAMES		0x04
 
 /* 48 bytes, what the demodulator + validator know about one frame */
 struct sora_adsb_frame {
@@ -113,6 +126,18 @@ struct sora_adsb_frame {
 			    * else see SORA_OPT_CORRECT_SINGLE_BIT */
     uint8_t flags;	   /* SORA_FRAME_* */
     uint8_t reserved;
+};
+
+/* 28 bytes: a frame as it crosses PCIe under SORA_OPT_WIRE_FRAMES */
+struct sora_adsb_wire_frame {
+    uint32_t bits[3];		/* message bits 0..95, MSB first */
+    uint32_t bits3_cb_flags;	/* bits 96..111 << 16 | corrected_bit (0xff: none)
+				 * << 8 | SORA_FRAME_* flags */
+    uint32_t position_lo;	/* position bits 31..0 */
+    uint32_t pos_hi_amp_hi;	/* position bits 39..32 << 24 | amplitude bits 55..32 */
+    uint32_t amp_lo;		/* amplitude bits 31..0: the integer A with
+				 * amplitude_56 = A * 2^-15 (uc8, sc8: A = sum56) or
+				 * A * 2^-31 (sc16), both exact */
 };
 
 struct sora_adsb_config {
@@ -256,6 +281,19 @@ int sora_adsb_collect(sora_adsb_ctx *ctx, struct sora_adsb_frame *out,
 	size_t cap, size_t *n);
 int sora_adsb_collect_device(sora_adsb_ctx *ctx, void *d_out, size_t cap,
 	size_t *n);
+
+/* The same for a context created with SORA_OPT_WIRE_FRAMES. */
+int sora_adsb_collect_wire(sora_adsb_ctx *ctx, struct sora_adsb_wire_frame *out,
+	size_t cap, size_t *n);
+int sora_adsb_collect_wire_device(sora_adsb_ctx *ctx, void *d_out, size_t cap,
+	size_t *n);
+/*
+ * Wire frames back into struct sora_adsb_frame, field for field what the
+ * context would have written without the option (host code, no device).
+ * `encoding`: the one the frames were scanned with (it scales the amplitude).
+ */
+int sora_adsb_unpack_frames(const struct sora_adsb_wire_frame *in, size_t n,
+	int encoding, struct sora_adsb_frame *out);
 
 int sora_adsb_get_counts(sora_adsb_ctx *ctx, struct sora_adsb_counts *out); /* syncs */
 /* How often this context has re-run a chunk with larger lists so far. */

@@ -24,6 +24,7 @@ EMIT_ACCEPTED, EMIT_CANDIDATES = 0, 1
 FRAME_LONG, FRAME_SQUITTER, FRAME_ACCEPTED, FRAME_CORRECTED = 1, 2, 4, 8
 OPT_CORRECT_SINGLE_BIT = 1
 OPT_FIXED_LISTS = 2
+OPT_WIRE_FRAMES = 4
 WINDOW, HALO = 240, 239
 NOALLOC_MAX_SAMPLES = 1 << 21
 NOALLOC_SCRATCH_BYTES = 38 << 20
@@ -57,6 +58,13 @@ FRAME_DTYPE = np.dtype([
     ("df", "u1"), ("corrected_bit", "i1"), ("flags", "u1"), ("reserved", "u1"),
 ])
 assert FRAME_DTYPE.itemsize == C.sizeof(Frame) == 48
+
+# struct sora_adsb_wire_frame (SORA_OPT_WIRE_FRAMES)
+WIRE_DTYPE = np.dtype([
+    ("bits", "<u4", (3,)), ("bits3_cb_flags", "<u4"), ("position_lo", "<u4"),
+    ("pos_hi_amp_hi", "<u4"), ("amp_lo", "<u4"),
+])
+assert WIRE_DTYPE.itemsize == 28
 
 
 class Config(C.Structure):
@@ -148,6 +156,11 @@ _SIGNATURES = {
                                     C.POINTER(C.c_size_t)]),
     "sora_adsb_collect_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t,
                                            C.POINTER(C.c_size_t)]),
+    "sora_adsb_collect_wire": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t,
+                                         C.POINTER(C.c_size_t)]),
+    "sora_adsb_collect_wire_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t,
+                                                C.POINTER(C.c_size_t)]),
+    "sora_adsb_unpack_frames": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     "sora_adsb_get_counts": (C.c_int, [C.c_void_p, C.POINTER(Counts)]),
     "sora_adsb_list_regrows": (C.c_int, [C.c_void_p]),
     "sora_adsb_synchronize": (C.c_int, [C.c_void_p]),

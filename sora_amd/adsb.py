@@ -4,8 +4,18 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import (BYTES_PER_SAMPLE, Config, Counts, EMIT_ACCEPTED, FRAME_DTYPE, check,
-                   lib)
+from ._lib import (BYTES_PER_SAMPLE, Config, Counts, EMIT_ACCEPTED, FRAME_DTYPE, WIRE_DTYPE,
+                   check, lib)
+
+
+def unpack_frames(wire, encoding):
+    """28-byte wire frames (SORA_OPT_WIRE_FRAMES) -> FRAME_DTYPE, on the host."""
+    wire = np.ascontiguousarray(wire)
+    out = np.zeros(wire.size, dtype=FRAME_DTYPE)
+    check(lib().sora_adsb_unpack_frames(wire.ctypes.data if wire.size else None, wire.size,
+                                        int(encoding),
+                                        out.ctypes.data if wire.size else None))
+    return out
 
 
 def _ptr(buf):
@@ -63,11 +73,17 @@ class AdsbContext:
 
     def __init__(self, max_chunk_samples, device=0, emit_mode=EMIT_ACCEPTED,
                  max_candidates=0, max_squitters=0, max_frames=0, stream=None,
-                 correct_single_bit=False, fixed_lists=False):
+                 correct_single_bit=False, fixed_lists=False, wire_frames=False):
         self.device = device
         options = _lib.OPT_CORRECT_SINGLE_BIT if correct_single_bit else 0
         if fixed_lists:
             options |= _lib.OPT_FIXED_LISTS
+        if wire_frames:
+            options |= _lib.OPT_WIRE_FRAMES
+        # what collect() and friends hand out: 48-byte frames, or 28-byte wire
+        # frames (unpack_frames() turns them into the former)
+        self.wire = bool(wire_frames)
+        self.frame_dtype = WIRE_DTYPE if wire_frames else FRAME_DTYPE
         cfg = Config(int(max_chunk_samples), int(max_candidates), int(max_squitters),
                      int(max_frames), int(emit_mode), options, stream)
         h = C.c_void_p()
@@ -196,23 +212,29 @@ class AdsbContext:
         finally:
             lib().sora_adsb_stream_end(self._h)
 
+    def _collect_fn(self, device=False):
+        L = lib()
+        if self.wire:
+            return L.sora_adsb_collect_wire_device if device else L.sora_adsb_collect_wire
+        return L.sora_adsb_collect_device if device else L.sora_adsb_collect
+
     def collect(self, cap=None):
-        """Frames of the last resolve as a numpy structured array (FRAME_DTYPE)."""
+        """Frames of the last resolve as a numpy structured array (self.frame_dtype)."""
         n = C.c_size_t()
+        fn = self._collect_fn()
         if cap is None:
             # ask for the count first, then fetch exactly that many
-            check(lib().sora_adsb_collect(self._h, None, 0, C.byref(n)), self._h)
+            check(fn(self._h, None, 0, C.byref(n)), self._h)
             cap = n.value
-        out = np.zeros(cap, dtype=FRAME_DTYPE)
-        check(lib().sora_adsb_collect(self._h, out.ctypes.data if cap else None, cap,
-                                      C.byref(n)), self._h)
+        out = np.zeros(cap, dtype=self.frame_dtype)
+        check(fn(self._h, out.ctypes.data if cap else None, cap, C.byref(n)), self._h)
         return out[:min(cap, n.value)]
 
     def collect_into(self, out):
         """Frames into a preallocated (ideally pinned) numpy array; returns count."""
         n = C.c_size_t()
-        check(lib().sora_adsb_collect(self._h, out.ctypes.data, out.size, C.byref(n)),
-              self._h)
+        assert out.dtype == self.frame_dtype
+        check(self._collect_fn()(self._h, out.ctypes.data, out.size, C.byref(n)), self._h)
         return n.value
 
     def frame_count(self):
@@ -224,8 +246,7 @@ class AdsbContext:
 
     def collect_device(self, d_out, cap):
         n = C.c_size_t()
-        check(lib().sora_adsb_collect_device(self._h, _ptr(d_out), cap, C.byref(n)),
-              self._h)
+        check(self._collect_fn(device=True)(self._h, _ptr(d_out), cap, C.byref(n)), self._h)
         return n.value
 
     def counts(self):

@@ -457,6 +457,7 @@ sora_adsb_scan(sora_adsb_ctx *ctx, const void *d_iq, size_t nbytes, int encoding
     r.regions = groups * r.filter_parts;
     r.acc_count = ctx->d_acc_count;
     r.acc_offset = ctx->d_acc_offset;
+    r.wire = (ctx->cfg.options & SORA_OPT_WIRE_FRAMES) != 0;
 
     ctx->groups = groups;
     bind_lists(ctx);
@@ -767,12 +768,16 @@ ensure_complete(sora_adsb_ctx *ctx, bool *overflow) {
 
 int
 collect_common(sora_adsb_ctx *ctx, void *dst, size_t cap, size_t *n,
-	hipMemcpyKind kind) {
+	hipMemcpyKind kind, bool wire) {
     bool overflow = false;
 
     if (ctx == nullptr || n == nullptr || (dst == nullptr && cap != 0))
 	return SORA_ERR_INVALID;
     *n = 0;
+    if (wire != ((ctx->cfg.options & SORA_OPT_WIRE_FRAMES) != 0))
+	return fail(ctx, SORA_ERR_STATE, wire? "this context was created without "
+		"SORA_OPT_WIRE_FRAMES" : "this context hands out wire frames: "
+		"sora_adsb_collect_wire");
     if (!ctx->resolved)
 	return fail(ctx, SORA_ERR_STATE, "collect without a resolve");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -787,8 +792,8 @@ collect_common(sora_adsb_ctx *ctx, void *dst, size_t cap, size_t *n,
     *n = (size_t) total;
     const size_t take = total < cap? (size_t) total : cap;
     if (take > 0) {
-	HIP_TRY(ctx, hipMemcpyAsync(dst, ctx->d_frames, take * sizeof(sora_adsb_frame),
-		kind, ctx->stream));
+	HIP_TRY(ctx, hipMemcpyAsync(dst, ctx->d_frames, take * (wire?
+		sizeof(sora_adsb_wire_frame) : sizeof(sora_adsb_frame)), kind, ctx->stream));
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
     return SORA_OK;
@@ -798,12 +803,72 @@ collect_common(sora_adsb_ctx *ctx, void *dst, size_t cap, size_t *n,
 
 extern "C" int
 sora_adsb_collect(sora_adsb_ctx *ctx, sora_adsb_frame *out, size_t cap, size_t *n) {
-    return collect_common(ctx, out, cap, n, hipMemcpyDeviceToHost);
+    return collect_common(ctx, out, cap, n, hipMemcpyDeviceToHost, false);
 }
 
 extern "C" int
 sora_adsb_collect_device(sora_adsb_ctx *ctx, void *d_out, size_t cap, size_t *n) {
-    return collect_common(ctx, d_out, cap, n, hipMemcpyDeviceToDevice);
+    return collect_common(ctx, d_out, cap, n, hipMemcpyDeviceToDevice, false);
+}
+
+extern "C" int
+sora_adsb_collect_wire(sora_adsb_ctx *ctx, sora_adsb_wire_frame *out, size_t cap, size_t *n) {
+    return collect_common(ctx, out, cap, n, hipMemcpyDeviceToHost, true);
+}
+
+extern "C" int
+sora_adsb_collect_wire_device(sora_adsb_ctx *ctx, void *d_out, size_t cap, size_t *n) {
+    return collect_common(ctx, d_out, cap, n, hipMemcpyDeviceToDevice, true);
+}
+
+/*
+ * Wire frames -> frames, on the host.  Everything a frame holds beyond the
+ * wire frame is a function of the bits: DF (plane.c:461), long (:462), the
+ * CRC-24 over the first 88 or 32 bits (:373-385) and with it syndrome and
+ * address (:472-480).  A corrected frame carries the corrected bits; the
+ * syndrome the device found before the flip is that of its one flipped bit,
+ * x^(n - 1 - b) mod G (adsb_tile.h).
+ */
+extern "C" int
+sora_adsb_unpack_frames(const sora_adsb_wire_frame *in, size_t n, int encoding,
+	sora_adsb_frame *out) {
+    const int bps = bytes_per_sample(encoding);
+    if (bps == 0 || ((in == nullptr || out == nullptr) && n != 0))
+	return SORA_ERR_INVALID;
+    for (size_t i = 0; i < n; i++) {
+	const sora_adsb_wire_frame &w = in[i];
+	sora_adsb_frame f;
+	memset(&f, 0, sizeof f);
+	f.bits[0] = w.bits[0];
+	f.bits[1] = w.bits[1];
+	f.bits[2] = w.bits[2];
+	f.bits[3] = w.bits3_cb_flags & 0xffff0000u;
+	f.flags = (uint8_t) (w.bits3_cb_flags & 0xffu);
+	f.corrected_bit = (int8_t) (uint8_t) ((w.bits3_cb_flags >> 8) & 0xffu);
+	f.position = ((uint64_t) (w.pos_hi_amp_hi >> 24) << 32) | w.position_lo;
+	const uint64_t amp = ((uint64_t) (w.pos_hi_amp_hi & 0xffffffu) << 32) | w.amp_lo;
+	f.amplitude_56 = (double) amp * (encoding == SORA_ENC_SC16? 1.0 / 2147483648.0 :
+		1.0 / 32768.0);
+	f.sum56 = encoding == SORA_ENC_SC16? 0 : (uint32_t) amp;
+	f.df = (uint8_t) (f.bits[0] >> 27);
+	const bool is_long = f.df >= 16 && f.df <= 24;
+	const int nbits = is_long? 112 : 56;
+	uint32_t crc = 0;
+	for (int k = 0; k < nbits - 24; k++) {
+	    crc = (crc << 1) ^ (((f.bits[k >> 5] >> (31 - (k & 31))) & 1u) << 24);
+	    if (crc & 0x1000000u)
+		crc ^= 0x1fff409u;
+	}
+	const uint32_t ap = is_long? (((f.bits[2] & 0xffu) << 16) | (f.bits[3] >> 16)) :
+		(f.bits[1] >> 8);
+	f.syndrome = (crc & 0xffffffu) ^ ap;
+	if (f.corrected_bit >= 0)
+	    f.syndrome ^= sora_crc_pow(nbits - 1 - f.corrected_bit);
+	const bool squitter = f.df == 11 || f.df == 17 || f.df == 18;
+	f.address = squitter? (f.bits[0] & 0xffffffu) : f.syndrome;
+	out[i] = f;
+    }
+    return SORA_OK;
 }
 
 extern "C" int
@@ -917,6 +982,9 @@ sora_adsb_stream_begin(sora_adsb_ctx *ctx, int encoding, uint64_t block_samples,
 		(unsigned long long) ctx->cfg.max_chunk_samples);
     if (ctx->st.active)
 	return fail(ctx, SORA_ERR_STATE, "a stream is already open");
+    if ((ctx->cfg.options & SORA_OPT_WIRE_FRAMES) != 0)
+	return fail(ctx, SORA_ERR_STATE, "the stream calls hand out struct sora_adsb_frame: "
+		"create the context without SORA_OPT_WIRE_FRAMES");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
 
     auto &s = ctx->st;

@@ -95,8 +95,10 @@ struct sora_resolve_args {
     uint32_t acc_cap;
     uint64_t *acc_offset;	/* [regions + 1] exclusive scan of clamped counts */
     uint64_t *acc_flat;		/* [frames_cap] the accepted records, flat */
-    struct sora_adsb_frame *frames;
+    struct sora_adsb_frame *frames;	/* wire != 0: struct sora_adsb_wire_frame */
     uint64_t frames_cap;
+    int32_t wire;		/* SORA_OPT_WIRE_FRAMES */
+    int32_t pad_;
 };
 
 #define SORA_SEEN_EMPTY		0xffffffffu

@@ -1432,7 +1432,7 @@ row_sum(double v) {
  * them, so the reference's in-order double accumulation (plane-iq.c:72-73)
  * never rounds either.
  */
-template <bool kWide> __device__ __forceinline__ void
+template <bool kWide, bool kWire> __device__ __forceinline__ void
 finalize_four(const sora_resolve_args &a, uint64_t f, bool valid, uint64_t r,
 	const frame_part<kWide> &part, uint32_t lane, const group_powers &pw,
 	uint32_t flip, bool any_corrected) {
@@ -1508,12 +1508,33 @@ finalize_four(const sora_resolve_args &a, uint64_t f, bool valid, uint64_t r,
     }
 
     double a56;
+    uint64_t amp;		/* the integer the amplitude is a multiple of */
     if constexpr (kWide) {
-	a56 = row_sum(dsum) * (1.0 / 2147483648.0);	/* float (s0+s1)/2, s = m * 2^-30 */
+	const double total = row_sum(dsum);		/* an integer below 2^40 */
+	a56 = total * (1.0 / 2147483648.0);		/* float (s0+s1)/2, s = m * 2^-30 */
+	amp = (uint64_t) total;
 	sum56 = 0;
     } else {
 	sum56 = row_sum(sum56);
 	a56 = (double) sum56 * (1.0 / 32768.0);		/* exact: see sora_adsb_frame */
+	amp = sum56;
+    }
+    if constexpr (kWire) {
+	if (valid && sub == 0) {
+	    const uint64_t pos = a.base_position + sora_rec_pos(r);
+	    const uint32_t flags = (is_long? SORA_FRAME_LONG : 0) |
+		    (squitter? SORA_FRAME_SQUITTER : 0) |
+		    (corrected >= 0? SORA_FRAME_CORRECTED : 0) |
+		    ((sora_rec_kind(r) & SORA_REC_ACCEPTED)? SORA_FRAME_ACCEPTED : 0);
+	    sora_adsb_wire_frame w;
+	    w.bits[0] = bits[0]; w.bits[1] = bits[1]; w.bits[2] = bits[2];
+	    w.bits3_cb_flags = (bits[3] & 0xffff0000u) | (((uint32_t) corrected & 0xffu) << 8) | flags;
+	    w.position_lo = (uint32_t) pos;
+	    w.pos_hi_amp_hi = ((uint32_t) (pos >> 32) << 24) | ((uint32_t) (amp >> 32) & 0xffffffu);
+	    w.amp_lo = (uint32_t) amp;
+	    reinterpret_cast<sora_adsb_wire_frame *>(a.frames)[f] = w;
+	}
+	return;
     }
     if (valid && sub == 0) {
 	sora_adsb_frame fr;
@@ -1543,7 +1564,7 @@ finalize_four(const sora_resolve_args &a, uint64_t f, bool valid, uint64_t r,
 #endif
 constexpr int kFinalizeDepth = 2;	/* rounds (of four frames) whose sample fetches are in flight */
 
-template <bool kWide>
+template <bool kWide, bool kWire>
 __global__ void __launch_bounds__(kSmall)
 finalize_kernel(sora_resolve_args a) {
     const uint32_t flip = a.encoding == SORA_ENC_UC8? 0x80808080u : 0u;
@@ -1587,8 +1608,8 @@ finalize_kernel(sora_resolve_args a) {
 #pragma unroll
 	    for (int u = 0; u < kFinalizeDepth; u++)
 		if (j + 4 * u < cnt)				/* wave-uniform */
-		    finalize_four<kWide>(a, batch + idx[u], idx[u] < cnt && sane[u], r[u], part[u],
-			    lane, pw, flip, any_corrected);
+		    finalize_four<kWide, kWire>(a, batch + idx[u], idx[u] < cnt && sane[u], r[u],
+			    part[u], lane, pw, flip, any_corrected);
 	}
     }
 }
@@ -1822,12 +1843,15 @@ sora_launch_finalize(const sora_resolve_args *a, uint32_t cus, hipStream_t strea
     /* SORA_FINALIZE_BLOCKS blocks of 4 waves per CU: every wave slot busy
      * hiding the two dependent fetches (record, then samples) of a frame */
     (void) hipGetLastError();
-    if (a->encoding == SORA_ENC_SC16)
-	hipLaunchKernelGGL(finalize_kernel<true>, dim3(cus * SORA_FINALIZE_BLOCKS), dim3(kSmall), 0,
-		stream, *a);
+    const dim3 grid(cus * SORA_FINALIZE_BLOCKS), block(kSmall);
+    if (a->encoding == SORA_ENC_SC16 && a->wire)
+	hipLaunchKernelGGL((finalize_kernel<true, true>), grid, block, 0, stream, *a);
+    else if (a->encoding == SORA_ENC_SC16)
+	hipLaunchKernelGGL((finalize_kernel<true, false>), grid, block, 0, stream, *a);
+    else if (a->wire)
+	hipLaunchKernelGGL((finalize_kernel<false, true>), grid, block, 0, stream, *a);
     else
-	hipLaunchKernelGGL(finalize_kernel<false>, dim3(cus * SORA_FINALIZE_BLOCKS), dim3(kSmall), 0,
-		stream, *a);
+	hipLaunchKernelGGL((finalize_kernel<false, false>), grid, block, 0, stream, *a);
     return hipGetLastError();
 }
 

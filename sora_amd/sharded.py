@@ -40,7 +40,12 @@ import torch.distributed as dist
 from . import _lib
 from ._lib import BYTES_PER_SAMPLE, FRAME_DTYPE, HALO
 
-FRAME_BYTES = FRAME_DTYPE.itemsize
+
+def _frame_dtype(ctx):
+    """What the context hands out: 48-byte frames, or 28-byte wire frames under
+    SORA_OPT_WIRE_FRAMES (sora_amd.unpack_frames turns them into the former)."""
+    return getattr(ctx, "frame_dtype", FRAME_DTYPE)
+
 HEADER_WORDS = 8                    # u64 per rank: seq, n_frames, ack (rank 0), pad
 EXCHANGE_RECORDS = 8192             # words of a rank's exchange block: count + records
 SPIN_TIMEOUT_S = 300.0
@@ -65,9 +70,10 @@ class LocalDecoder:
 
     def __init__(self, ctx, max_frames, pin=True):
         self.ctx = ctx
-        self.h_pin = torch.empty(int(max_frames) * FRAME_BYTES, dtype=torch.uint8,
+        self.dtype = _frame_dtype(ctx)
+        self.h_pin = torch.empty(int(max_frames) * self.dtype.itemsize, dtype=torch.uint8,
                                  pin_memory=pin)
-        self.h_frames = self.h_pin.numpy().view(FRAME_DTYPE)
+        self.h_frames = self.h_pin.numpy().view(self.dtype)
         self.n = 0
 
     def begin(self, d_iq, nbytes, encoding, base_position, n_owned, reset=True):
@@ -106,6 +112,8 @@ class ShardedDecoder:
     def __init__(self, ctx, rank, world, device, max_frames, group=None, stream=None,
                  gather="shm", exchange_records=EXCHANGE_RECORDS):
         self.ctx, self.rank, self.world = ctx, rank, world
+        self.dtype = _frame_dtype(ctx)
+        self.frame_bytes = self.dtype.itemsize
         self.device, self.max_frames, self.group = device, int(max_frames), group
         self.stream, self.gather = stream, gather
         self.cuda = device.type == "cuda"
@@ -124,7 +132,7 @@ class ShardedDecoder:
                                          pin_memory=True)
         self.h_exported = torch.zeros(world, dtype=torch.int64, pin_memory=self.cuda)
         self.counts = torch.zeros(world, dtype=torch.int64, device=device)
-        self.d_out = torch.zeros(self.max_frames * FRAME_BYTES, dtype=torch.uint8,
+        self.d_out = torch.zeros(self.max_frames * self.frame_bytes, dtype=torch.uint8,
                                  device=device)
         self.seq = 0
         self.ns = [0] * world
@@ -136,13 +144,13 @@ class ShardedDecoder:
             self.d_gather = ([torch.zeros_like(self.d_out) for _ in range(world)]
                              if rank == 0 else None)
             n_host = self.max_frames * (world if rank == 0 else 1)
-            self.h_pin = torch.empty(n_host * FRAME_BYTES, dtype=torch.uint8,
+            self.h_pin = torch.empty(n_host * self.frame_bytes, dtype=torch.uint8,
                                      pin_memory=self.cuda)
-            self.h_frames = self.h_pin.numpy().view(FRAME_DTYPE)
+            self.h_frames = self.h_pin.numpy().view(self.dtype)
 
     # -- the shared host segment -------------------------------------------
     def _open_segment(self):
-        self.slot_bytes = max(1, self.max_frames) * FRAME_BYTES
+        self.slot_bytes = max(1, self.max_frames) * self.frame_bytes
         self.slot_bytes += -self.slot_bytes % 4096
         self.data_at = 4096                      # the header has a page of its own
         nbytes = self.data_at + self.world * self.slot_bytes
@@ -168,7 +176,7 @@ class ShardedDecoder:
             self.world, HEADER_WORDS)
         self.slots = [self._mm[self.data_at + r * self.slot_bytes:
                                self.data_at + r * self.slot_bytes +
-                               self.max_frames * FRAME_BYTES].view(FRAME_DTYPE)
+                               self.max_frames * self.frame_bytes].view(self.dtype)
                       for r in range(self.world)]
         if self.cuda:
             idx = self.device.index if self.device.index is not None else 0
@@ -178,7 +186,7 @@ class ShardedDecoder:
         if self._registered is None:
             # the segment cannot be page-locked here (RLIMIT_MEMLOCK, containers):
             # DMA into a pinned buffer of this rank, then a CPU copy into the slot
-            self.h_stage_t = torch.empty(self.max_frames * FRAME_BYTES, dtype=torch.uint8,
+            self.h_stage_t = torch.empty(self.max_frames * self.frame_bytes, dtype=torch.uint8,
                                          pin_memory=self.cuda)
             base = self.data_at + self.rank * self.slot_bytes
             self.h_slot_t = torch.from_numpy(self._mm)[base:base + self.slot_bytes]
@@ -270,7 +278,7 @@ class ShardedDecoder:
             n = ctx.collect_device(self.d_out, self.max_frames)
             if n > self.max_frames:
                 raise RuntimeError(f"{n} frames exceed max_frames")
-            total = n * FRAME_BYTES
+            total = n * self.frame_bytes
             cuts = list(range(0, total, 16 << 20)) + [total]
             events = []
             for a, b in zip(cuts, cuts[1:]):
@@ -302,7 +310,7 @@ class ShardedDecoder:
         if max(ns) > self.max_frames:
             raise RuntimeError(f"{max(ns)} frames exceed max_frames")
         self.ns = ns
-        m = max(ns) * FRAME_BYTES
+        m = max(ns) * self.frame_bytes
         if m and self.stage_exchange:           # gloo: through host memory
             mine = self.d_out[:m].cpu()
             parts = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
@@ -316,7 +324,7 @@ class ShardedDecoder:
         if rank == 0:
             off = 0
             for r in range(world):
-                nb = ns[r] * FRAME_BYTES
+                nb = ns[r] * self.frame_bytes
                 self.h_pin[off:off + nb].copy_(self.d_gather[r][:nb], non_blocking=True)
                 off += nb
             if self.cuda:

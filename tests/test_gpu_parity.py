@@ -542,6 +542,53 @@ def test_stream_empty_and_errors():
         assert_same_frames(got, [c for c in ob.scan(raw) if c["accepted"]])
 
 
+@pytest.mark.parametrize("enc", [ENC_UC8, ENC_SC8, ENC_SC16])
+def test_wire_frames_unpack_to_the_same_frames(enc):
+    """SORA_OPT_WIRE_FRAMES: 28 bytes per frame over PCIe; sora_adsb_unpack_frames
+    gives back the 48-byte frame, field for field (every byte), for every
+    candidate of mixed traffic, with and without single-bit correction."""
+    p = synth.default_params(4 if enc == ENC_SC16 else 2, n_samples=700000, mean_gap=500,
+                             reply_permille=300, unknown_permille=200, n_icao=6, seed=71)
+    p.encoding = enc
+    if enc != ENC_SC16:
+        p.flip_permille = 200
+        p.amp_min, p.amp_max = 30, 110
+    raw = synth.fill_host(p.n_samples, enc, p.seed, synth.make_frames(p)).tobytes()
+    n = p.n_samples
+    for emit, fix in ((EMIT_CANDIDATES, True), (EMIT_ACCEPTED, False)):
+        kw = dict(emit_mode=emit, max_candidates=n // 2, max_squitters=n // 2,
+                  correct_single_bit=fix)
+        with AdsbContext(n, **kw) as ctx:
+            ctx.submit_host(raw, enc)
+            full = ctx.collect()
+            with pytest.raises(sora_amd.SoraError):
+                ctx._collect_fn = lambda device=False: sora_amd._lib.lib().sora_adsb_collect_wire
+                ctx.collect()                       # not a wire context
+        with AdsbContext(n, wire_frames=True, **kw) as ctx:
+            ctx.submit_host(raw, enc)
+            wire = ctx.collect()
+            assert wire.dtype.itemsize == 28
+            with pytest.raises(sora_amd.SoraError):
+                list(ctx.stream(raw, enc, 100000))  # the stream calls hand out full frames
+        back = sora_amd.unpack_frames(wire, enc)
+        assert len(full) > 500 and back.tobytes() == full.tobytes()
+        if fix:
+            assert (full["corrected_bit"] >= 0).sum() > 20
+    # positions beyond 2^32 and the largest amplitudes survive the packing
+    raw = sc16_noise(5, 20000, 30000) if enc == ENC_SC16 else bytes([0, 0, 255, 255] * 10000)
+    base = (1 << 39) + 123456
+    for wire_mode in (False, True):
+        with AdsbContext(20000, emit_mode=EMIT_CANDIDATES, wire_frames=wire_mode) as ctx:
+            ctx.submit_host(raw, enc, base_position=base)
+            got = ctx.collect()
+        if wire_mode:
+            assert sora_amd.unpack_frames(got, enc).tobytes() == ref.tobytes()
+        else:
+            ref = got
+    if enc == ENC_SC16:
+        assert len(ref) > 100 and ref["amplitude_56"].max() > 56 * 0.5
+
+
 def test_stream_source_failure_is_not_end_of_stream():
     """An exception inside the read callback (ctypes would swallow it and the
     library would see a short read = end of stream) reaches the caller."""

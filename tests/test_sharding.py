@@ -279,8 +279,12 @@ def test_two_gpu_processes_small_lists_and_block_overflow(tmp_path):
     want = [c for c in ob.scan(raw) if c["accepted"]]
     out = str(tmp_path / "frames.npy")
     mp.spawn(_worker, args=(2, _free_port(), raw, out, "shm", 64, True, 20000,
-                            {"max_candidates": 16, "max_frames": 16}), nprocs=2, join=True)
-    _same_as_oracle(np.load(out), want)
+                            {"max_candidates": 16, "max_frames": 16, "wire_frames": True}),
+             nprocs=2, join=True)
+    import sora_amd                      # 28-byte wire frames through the segment
+    got = np.load(out)
+    assert got.dtype.itemsize == 28
+    _same_as_oracle(sora_amd.unpack_frames(got, ob.ENC_UC8), want)
     assert all(int(open(f"{out}.{r}.regrows").read()) >= 2 for r in range(2))
     out2 = str(tmp_path / "frames2.npy")
     mp.spawn(_overflow_worker, args=(2, _free_port(), raw, out2, True), nprocs=2, join=True)
