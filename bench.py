@@ -262,13 +262,13 @@ def main():
     def run(k):
         """k steps, pipelined over the decoders; returns the last frame count.
 
-        Kernels of different captures never share the GPU (a scan whose static
-        tile ranges compete with another capture's resolve gets stragglers):
-        events put them in the order S(i), R(i-1), S(i+1), R(i), ...  What
-        overlaps a scan is host work and copies: with two decoders the previous
-        capture's frame copy, with three also the previous capture's exchange
-        (squitter records over RCCL, N>1), whose host-side waits would otherwise
-        leave the GPU idle between a scan and its resolve."""
+        Kernels of different captures never share the GPU (measured again in
+        round 2 with a scan at 3, 4 and 5 waves per SIMD: a scan that shares the
+        CUs with a resolve takes as much longer as the resolve takes): events
+        put them in the order S(i), R(i), S(i+1), R(i+1), ...  What overlaps a
+        scan is the previous capture's frame copy to the host and the host's
+        wait for it.  (--inflight 3 is the older schedule that moves the N>1
+        exchange under the next scan.)"""
         n_dec, n = len(decs), 0
         if n_dec >= 3:
             scanned, resolved = {}, {}
@@ -295,11 +295,16 @@ def main():
             if resolved is not None and not args.overlap:
                 streams[i % n_dec].wait_event(resolved)    # S(i) behind R(i-1)
             timed("begin", d.begin, *job)  # reset (a new capture) + scan, asynchronous
-            if prev is not None:
-                n = finish(prev)
-            timed("exchange", d.exchange)  # (N>1: squitter exchange) + resolve
+            # (N>1: squitter exchange) + resolve, queued right behind the scan: the
+            # GPU goes from one to the other without waiting for the host, which
+            # meanwhile waits for the PREVIOUS capture's frames (until round 2 the
+            # host queued this after that wait: 0.17 ms of idle GPU per step and
+            # launch gaps between the small kernels, seen in the kernel trace)
+            timed("exchange", d.exchange)
             if n_dec > 1:
                 resolved = mark(i)
+            if prev is not None:
+                n = finish(prev)
             prev = d
         if prev is not None:
             n = finish(prev)

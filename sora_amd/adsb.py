@@ -238,11 +238,11 @@ class AdsbContext:
         return n.value
 
     def frame_count(self):
-        """Frames the last resolve produced (waits for it)."""
-        c = self.counts()
-        if c["overflow"]:
-            raise _lib.SoraError(_lib.ERR_OVERFLOW, "a device list overflowed")
-        return int(c["frames"])
+        """Frames the last resolve produced (waits for it; lists that overflowed
+        are grown and the chunk run again first)."""
+        n = C.c_size_t()
+        check(self._collect_fn()(self._h, None, 0, C.byref(n)), self._h)
+        return n.value
 
     def collect_device(self, d_out, cap):
         n = C.c_size_t()

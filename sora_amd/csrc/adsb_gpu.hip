@@ -40,6 +40,15 @@ struct sora_adsb_ctx {
     uint8_t *d_stage;
     size_t stage_bytes;
 
+    /* what a collect reads first (sora_resolve_args::summary) and its pinned
+     * mirror: one 32-byte copy tells whether every list held and how many frames
+     * there are; the per-region counters below are fetched only when one did not,
+     * and for sora_adsb_get_counts */
+    uint64_t *d_summary, *h_summary;
+    /* epoch of the first-seen table (sora_resolve_args::seen_tag): a reset is a
+     * new tag, not 128 MB of stores */
+    uint32_t epoch;
+
     /* host mirrors */
     uint32_t *h_counts;		/* 2 * max_groups + max_regions */
     uint64_t *h_stats;		/* max_groups * SORA_STAT_WORDS */
@@ -111,6 +120,7 @@ void stream_release(sora_adsb_ctx *ctx);
     } while (0)
 
 constexpr uint32_t kScanRounds = 16;	/* rounds of scan workgroups per CU */
+constexpr uint64_t kSummaryAlloc = 32;	/* words behind d_summary: zeroed 256 bytes at a time */
 constexpr uint32_t kMinTiles = 8;	/* tiles per workgroup, at least */
 
 uint32_t
@@ -259,6 +269,9 @@ sora_adsb_destroy(sora_adsb_ctx *ctx) {
     (void) hipFree(ctx->d_sq_count);
     (void) hipFree(ctx->d_acc_count);
     (void) hipFree(ctx->d_stage);
+    (void) hipFree(ctx->d_summary);
+    if (ctx->h_summary != nullptr)
+	(void) hipHostFree(ctx->h_summary);
     if (ctx->h_counts != nullptr)
 	(void) hipHostFree(ctx->h_counts);
     if (ctx->h_stats != nullptr)
@@ -272,13 +285,32 @@ sora_adsb_destroy(sora_adsb_ctx *ctx) {
     free(ctx);
 }
 
+namespace {
+
+constexpr uint32_t kLastEpoch = 0xfffffeu;
+
+uint64_t
+seen_tag(const sora_adsb_ctx *ctx) {
+    return (uint64_t) (0xffffffu - ctx->epoch) << 40;
+}
+
+} /* namespace */
+
 extern "C" int
 sora_adsb_reset(sora_adsb_ctx *ctx) {
     if (ctx == nullptr)
 	return SORA_ERR_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, sora_launch_fill_u64(ctx->d_first_seen, ~0ull, SORA_ADDRESSES,
-	    ctx->stream));
+    /* forgetting every address = the next epoch: what the table holds is then
+     * larger than anything stored or asked from now on (sora_resolve_args::
+     * seen_tag).  Only the first use and a wrap of the 24-bit epoch fill it. */
+    if (ctx->epoch == 0 || ctx->epoch >= kLastEpoch) {
+	HIP_TRY(ctx, sora_launch_fill_u64(ctx->d_first_seen, ~0ull, SORA_ADDRESSES,
+		ctx->stream));
+	ctx->epoch = 1;
+    } else {
+	ctx->epoch++;
+    }
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_known_bits, 0, SORA_KNOWN_WORDS * sizeof(uint32_t),
 	    ctx->stream));
     ctx->scanned = ctx->resolved = false;
@@ -362,8 +394,11 @@ sora_adsb_create(sora_adsb_ctx **out, int device, const sora_adsb_config *cfg) {
 	    dev_alloc(&ctx->d_export, ctx->export_cap) != hipSuccess ||
 	    dev_alloc(&ctx->d_rec_count, g) != hipSuccess ||
 	    dev_alloc(&ctx->d_sq_count, g) != hipSuccess ||
-	    dev_alloc(&ctx->d_acc_count, nr) != hipSuccess)
+	    dev_alloc(&ctx->d_acc_count, nr) != hipSuccess ||
+	    dev_alloc(&ctx->d_summary, kSummaryAlloc) != hipSuccess)
 	return fail(ctx, SORA_ERR_NOMEM, "hipMalloc of the device lists failed");
+    HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_summary),
+	    SORA_SUM_WORDS * sizeof(uint64_t), hipHostMallocDefault));
     HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_counts),
 	    (2 * (size_t) g + nr) * sizeof(uint32_t), hipHostMallocDefault));
     HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_stats),
@@ -437,7 +472,9 @@ sora_adsb_scan(sora_adsb_ctx *ctx, const void *d_iq, size_t nbytes, int encoding
 	a.first_seen = ctx->d_first_seen;
 	a.known_bits = ctx->d_known_bits;
 	a.base_position = base_position;
+	a.seen_tag = seen_tag(ctx);
     }
+    a.summary = ctx->d_summary;
 
     sora_resolve_args &r = ctx->res;
     memset(&r, 0, sizeof r);
@@ -453,6 +490,8 @@ sora_adsb_scan(sora_adsb_ctx *ctx, const void *d_iq, size_t nbytes, int encoding
     r.sq_count = ctx->d_sq_count;
     r.first_seen = ctx->d_first_seen;
     r.known_bits = ctx->d_known_bits;
+    r.seen_tag = seen_tag(ctx);
+    r.summary = ctx->d_summary;
     r.filter_parts = sora_filter_parts(groups);
     r.regions = groups * r.filter_parts;
     r.acc_count = ctx->d_acc_count;
@@ -472,6 +511,8 @@ sora_adsb_scan(sora_adsb_ctx *ctx, const void *d_iq, size_t nbytes, int encoding
     ctx->last.base_position = base_position;
     ctx->last.n_owned = n_owned;
 
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_summary, 0, kSummaryAlloc * sizeof(uint64_t),
+	    ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_scan_begin, ctx->stream));
     HIP_TRY(ctx, sora_launch_scan(&a, groups, (int) ctx->scan_variant, ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_scan_end, ctx->stream));
@@ -542,7 +583,7 @@ sora_adsb_add_known(sora_adsb_ctx *ctx, const void *d_records, size_t n_records)
     if (ctx == nullptr || (d_records == nullptr && n_records != 0))
 	return SORA_ERR_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, sora_launch_add_known(ctx->d_first_seen, ctx->d_known_bits,
+    HIP_TRY(ctx, sora_launch_add_known(ctx->d_first_seen, ctx->d_known_bits, seen_tag(ctx),
 	    static_cast<const uint64_t *>(d_records), n_records, ctx->stream));
     return SORA_OK;
 }
@@ -574,7 +615,7 @@ sora_adsb_add_known_blocks(sora_adsb_ctx *ctx, const void *d_blocks, size_t n_bl
 	return SORA_ERR_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, sora_launch_add_known_blocks(ctx->d_first_seen, ctx->d_known_bits,
-	    static_cast<const uint64_t *>(d_blocks), (uint32_t) n_blocks,
+	    seen_tag(ctx), static_cast<const uint64_t *>(d_blocks), (uint32_t) n_blocks,
 	    (uint32_t) block_records, skip_block < 0? 0xffffffffu : (uint32_t) skip_block,
 	    ctx->stream));
     return SORA_OK;
@@ -593,7 +634,7 @@ sora_adsb_resolve(sora_adsb_ctx *ctx) {
     }
     HIP_TRY(ctx, sora_launch_filter(&ctx->res, ctx->stream));
     HIP_TRY(ctx, sora_launch_scan_counts(ctx->d_acc_count, ctx->res.acc_cap,
-	    ctx->d_acc_offset, ctx->res.regions, ctx->stream));
+	    ctx->d_acc_offset, ctx->res.regions, ctx->d_summary + SORA_SUM_FRAMES, ctx->stream));
     HIP_TRY(ctx, sora_launch_finalize(&ctx->res, ctx->cus, ctx->stream));
     ctx->resolved = true;
     return SORA_OK;
@@ -760,6 +801,8 @@ ensure_complete(sora_adsb_ctx *ctx, bool *overflow) {
 		return rc;
 	} else {
 	    bind_lists(ctx);
+	    HIP_TRY(ctx, hipMemsetAsync(ctx->d_summary + SORA_SUM_ACC_OVER, 0, sizeof(uint64_t),
+		    ctx->stream));
 	}
 	if (was_resolved && (rc = sora_adsb_resolve(ctx)) != SORA_OK)
 	    return rc;
@@ -781,13 +824,24 @@ collect_common(sora_adsb_ctx *ctx, void *dst, size_t cap, size_t *n,
     if (!ctx->resolved)
 	return fail(ctx, SORA_ERR_STATE, "collect without a resolve");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    int rc = ensure_complete(ctx, &overflow);
-    if (rc != SORA_OK)
-	return rc;
-    if (overflow)
-	return fail(ctx, SORA_ERR_OVERFLOW,
-		"a device list overflowed and could not be grown; raise max_candidates / "
-		"max_squitters / max_frames (see sora_adsb_get_counts)");
+    /* the common case in one small copy: every list held */
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_summary, ctx->d_summary,
+	    SORA_SUM_WORDS * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->h_summary[SORA_SUM_REC_OVER] != 0 || ctx->h_summary[SORA_SUM_SQ_OVER] != 0 ||
+	    ctx->h_summary[SORA_SUM_ACC_OVER] != 0 ||
+	    ctx->h_summary[SORA_SUM_FRAMES] > ctx->frames_cap) {
+	/* one did not: every region's counters, larger lists, the chunk again */
+	int rc = ensure_complete(ctx, &overflow);
+	if (rc != SORA_OK)
+	    return rc;
+	if (overflow)
+	    return fail(ctx, SORA_ERR_OVERFLOW,
+		    "a device list overflowed and could not be grown; raise max_candidates / "
+		    "max_squitters / max_frames (see sora_adsb_get_counts)");
+    } else {
+	ctx->h_total[1] = ctx->h_summary[SORA_SUM_FRAMES];
+    }
     const uint64_t total = ctx->h_total[1];
     *n = (size_t) total;
     const size_t take = total < cap? (size_t) total : cap;
@@ -1046,21 +1100,19 @@ sora_adsb_stream_next(sora_adsb_ctx *ctx, const sora_adsb_frame **frames, size_t
     if (!s.last[cur] && (rc = stream_fill(ctx, cur ^ 1)) != SORA_OK)
 	return rc;
     /* waits for the block; a list that overflowed is grown and the block run
-     * again (ensure_complete), and the pinned frame buffer follows */
-    bool overflow = false;
-    if ((rc = ensure_complete(ctx, &overflow)) != SORA_OK)
-	return rc;
-    if (!overflow && ctx->h_total[1] > s.out_cap[cur]) {
+     * again (inside the collect), and the pinned frame buffer follows */
+    size_t got = 0;
+    rc = sora_adsb_collect(ctx, s.h_out[cur], (size_t) s.out_cap[cur], &got);
+    if (rc == SORA_OK && got > s.out_cap[cur]) {
 	(void) hipHostFree(s.h_out[cur]);
 	s.h_out[cur] = nullptr;
-	s.out_cap[cur] = ctx->frames_cap;
+	s.out_cap[cur] = ctx->frames_cap > got? ctx->frames_cap : got;
 	if (hipHostMalloc(reinterpret_cast<void **>(&s.h_out[cur]),
 		(size_t) s.out_cap[cur] * sizeof(sora_adsb_frame), hipHostMallocDefault) != hipSuccess)
 	    return fail(ctx, SORA_ERR_NOMEM, "pinned buffer for %llu frames",
 		    (unsigned long long) s.out_cap[cur]);
+	rc = sora_adsb_collect(ctx, s.h_out[cur], (size_t) s.out_cap[cur], &got);
     }
-    size_t got = 0;
-    rc = sora_adsb_collect(ctx, s.h_out[cur], (size_t) s.out_cap[cur], &got);
     if (rc != SORA_OK)
 	return rc;
     *frames = s.h_out[cur];

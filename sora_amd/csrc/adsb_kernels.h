@@ -55,6 +55,8 @@ struct sora_scan_args {
     uint64_t *first_seen;
     uint32_t *known_bits;
     uint64_t base_position;
+    uint64_t seen_tag;		/* see sora_resolve_args */
+    uint64_t *summary;		/* see sora_resolve_args; NULL: none */
 };
 
 /* does this scan kernel merge its squitters itself? */
@@ -88,6 +90,17 @@ struct sora_resolve_args {
     uint32_t *seen_keys;
     uint32_t seen_mask;
     uint32_t *seen_fail;	/* set when the table is full (an address was dropped) */
+    /* Epoch of the first-seen table, in bits 63..40 of every entry (positions
+     * stay below 2^40): a reset takes the next, SMALLER tag instead of refilling
+     * 128 MB -- entries of earlier epochs are larger than anything this epoch
+     * stores or compares with, so atomicMin replaces them and `entry < tag | P'
+     * is false for them, as for the all-ones entry of an address never seen. */
+    uint64_t seen_tag;
+    /* What the host needs to know before it copies the frames, in four words
+     * (SORA_SUM_*), zeroed when the scan starts: the largest count of a region
+     * that did not fit its share of a list (0: every one did) and the number of
+     * frames.  One 32-byte copy instead of every region's counters. */
+    uint64_t *summary;
     uint32_t regions;		/* accepted regions: groups * filter_parts */
     uint32_t filter_parts;	/* sora_filter_parts(groups) */
     uint64_t *acc;		/* [regions][acc_cap] accepted records */
@@ -102,6 +115,12 @@ struct sora_resolve_args {
 };
 
 #define SORA_SEEN_EMPTY		0xffffffffu
+
+#define SORA_SUM_REC_OVER	0	/* max records of a scan region beyond rec_cap */
+#define SORA_SUM_SQ_OVER	1	/* ... squitters beyond sq_cap */
+#define SORA_SUM_ACC_OVER	2	/* ... accepted records of a region beyond acc_cap */
+#define SORA_SUM_FRAMES		3	/* acc_offset[regions]: frames available */
+#define SORA_SUM_WORDS		4
 
 #define SORA_REGION_POS_BITS	22	/* a workgroup's tile range spans fewer positions */
 
@@ -121,12 +140,12 @@ hipError_t sora_launch_first_seen(const struct sora_resolve_args *a,
 	hipStream_t stream);
 /* same from flat global records (position << 24 | address) */
 hipError_t sora_launch_add_known(uint64_t *first_seen, uint32_t *known_bits,
-	const uint64_t *records, uint64_t n, hipStream_t stream);
+	uint64_t seen_tag, const uint64_t *records, uint64_t n, hipStream_t stream);
 /* same from n_blocks exchange blocks of `stride` words (word 0: record count,
  * read on the device), leaving out block `skip` */
 hipError_t sora_launch_add_known_blocks(uint64_t *first_seen, uint32_t *known_bits,
-	const uint64_t *blocks, uint32_t n_blocks, uint32_t stride, uint32_t skip,
-	hipStream_t stream);
+	uint64_t seen_tag, const uint64_t *blocks, uint32_t n_blocks, uint32_t stride,
+	uint32_t skip, hipStream_t stream);
 /* per address the earliest squitter of this scan (needs first_seen) -> flat
  * global records, unordered; *counter = how many there are (may exceed cap) */
 hipError_t sora_launch_export_first(const struct sora_resolve_args *a, uint64_t *dst,
@@ -137,8 +156,10 @@ hipError_t sora_launch_filter(const struct sora_resolve_args *a,
  * into status[0..1], on the device (SORA_NOALLOC_* in sora_adsb_gpu.h) */
 hipError_t sora_launch_noalloc_status(const struct sora_resolve_args *a,
 	uint64_t cap_frames, uint64_t *status, hipStream_t stream);
+/* offsets[i] = sum of the clamped counts before i; offsets[n] and, if not NULL,
+ * *total = their sum */
 hipError_t sora_launch_scan_counts(const uint32_t *counts, uint32_t cap,
-	uint64_t *offsets, uint32_t n, hipStream_t stream);
+	uint64_t *offsets, uint32_t n, uint64_t *total, hipStream_t stream);
 uint32_t sora_filter_parts(uint32_t groups);		/* accepted regions per scan region */
 uint32_t sora_filter_max_regions(uint32_t max_groups);
 /* flattens the accepted regions (needs acc_offset) and re-slices the frames */

@@ -198,8 +198,17 @@ merge_squitter_list(const sora_scan_args &a, const uint64_t *sq_out, uint32_t n,
 	const uint64_t r = __hip_atomic_load(&sq_out[i], __ATOMIC_RELAXED,
 		__HIP_MEMORY_SCOPE_AGENT);
 	note_known(a.first_seen, a.known_bits, sora_rec_addr(r),
-		a.base_position + sora_rec_pos(r));
+		a.seen_tag | (a.base_position + sora_rec_pos(r)));
     }
+}
+
+/* a region that did not fit its share of a list says so (sora_resolve_args::
+ * summary); nothing is written when everything fits */
+__device__ __forceinline__ void
+note_overflow(uint64_t *summary, int word, uint32_t count, uint32_t cap) {
+    if (summary != nullptr && count > cap)
+	atomicMax(reinterpret_cast<unsigned long long *>(&summary[word]),
+		(unsigned long long) count);
 }
 
 template <bool kWide>
@@ -517,6 +526,8 @@ adsb_scan_kernel(sora_scan_args a) {
     if (tid == 0) {
 	a.rec_count[group] = n_rec;
 	a.sq_count[group] = s_sq_total;
+	note_overflow(a.summary, SORA_SUM_REC_OVER, n_rec, a.rec_cap);
+	note_overflow(a.summary, SORA_SUM_SQ_OVER, s_sq_total, a.sq_cap);
     }
     /* statistics: st_cand is workgroup-uniform, the others wave-uniform */
     {
@@ -859,6 +870,8 @@ adsb_scan_direct_kernel(sora_scan_args a) {
     if (tid == 0) {
 	a.rec_count[group] = n_rec;
 	a.sq_count[group] = n_sq;
+	note_overflow(a.summary, SORA_SUM_REC_OVER, n_rec, a.rec_cap);
+	note_overflow(a.summary, SORA_SUM_SQ_OVER, n_sq, a.sq_cap);
     }
     {
 	__shared__ uint32_t s_stat[kWaves][3];
@@ -902,7 +915,7 @@ adsb_scan_direct_kernel(sora_scan_args a) {
 	    }
 	    if (a.first_seen != nullptr)
 		note_known(a.first_seen, a.known_bits, sora_rec_addr(r),
-			a.base_position + sora_rec_pos(r));
+			a.seen_tag | (a.base_position + sora_rec_pos(r)));
 	}
     }
 }
@@ -1009,23 +1022,23 @@ first_seen_kernel(sora_resolve_args a) {
 	n = a.sq_cap;
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
 	uint64_t r = sq[i];
+	const uint64_t position = a.seen_tag | (a.base_position + sora_rec_pos(r));
 	if constexpr (kHashed)
-	    note_known_hashed(a, sora_rec_addr(r), a.base_position + sora_rec_pos(r));
+	    note_known_hashed(a, sora_rec_addr(r), position);
 	else
-	    note_known(a.first_seen, a.known_bits, sora_rec_addr(r),
-		    a.base_position + sora_rec_pos(r));
+	    note_known(a.first_seen, a.known_bits, sora_rec_addr(r), position);
     }
 }
 
 __global__ void
-add_known_kernel(uint64_t *first_seen, uint32_t *known_bits,
+add_known_kernel(uint64_t *first_seen, uint32_t *known_bits, uint64_t seen_tag,
 	const uint64_t *records, uint64_t n) {
     uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t stride = (uint64_t) gridDim.x * blockDim.x;
 
     for (; i < n; i += stride) {
 	uint64_t r = records[i];
-	note_known(first_seen, known_bits, (uint32_t) r & 0xffffffu, r >> 24);
+	note_known(first_seen, known_bits, (uint32_t) r & 0xffffffu, seen_tag | (r >> 24));
     }
 }
 
@@ -1036,7 +1049,7 @@ add_known_kernel(uint64_t *first_seen, uint32_t *known_bits,
  * the collective and the resolve.  Block `skip` (this shard's own) is left out.
  */
 __global__ void
-add_known_blocks_kernel(uint64_t *first_seen, uint32_t *known_bits,
+add_known_blocks_kernel(uint64_t *first_seen, uint32_t *known_bits, uint64_t seen_tag,
 	const uint64_t *blocks, uint32_t stride, uint32_t skip) {
     const uint32_t b = blockIdx.y;
     if (b == skip)
@@ -1048,7 +1061,7 @@ add_known_blocks_kernel(uint64_t *first_seen, uint32_t *known_bits,
     for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n;
 	    i += (uint64_t) gridDim.x * blockDim.x) {
 	const uint64_t r = blk[1 + i];
-	note_known(first_seen, known_bits, (uint32_t) r & 0xffffffu, r >> 24);
+	note_known(first_seen, known_bits, (uint32_t) r & 0xffffffu, seen_tag | (r >> 24));
     }
 }
 
@@ -1062,7 +1075,7 @@ add_known_blocks_kernel(uint64_t *first_seen, uint32_t *known_bits,
 template <bool kNarrow>
 __global__ void __launch_bounds__(1024)
 scan_counts_kernel(const uint32_t *counts, uint32_t cap, uint64_t *offsets,
-	uint32_t n) {
+	uint32_t n, uint64_t *total) {
     __shared__ uint64_t s_wave[16];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t per = ((n + 1023) / 1024) * 64;	/* counts per wave */
@@ -1120,8 +1133,11 @@ scan_counts_kernel(const uint32_t *counts, uint32_t cap, uint64_t *offsets,
 		    __shfl(incl, 63, 64);
 	}
     }
-    if (tid == 1023)
+    if (tid == 1023) {
 	offsets[n] = base;	/* the last wave's base has passed every count */
+	if (total != nullptr)
+	    *total = base;
+    }
 }
 
 /*
@@ -1144,7 +1160,7 @@ export_first_kernel(sora_resolve_args a, uint64_t *dst, uint64_t dst_cap,
 	const uint64_t r = sq[i];
 	const uint64_t position = a.base_position + sora_rec_pos(r);
 	const uint32_t addr = sora_rec_addr(r);
-	if (a.first_seen[addr] == position) {
+	if (a.first_seen[addr] == (a.seen_tag | position)) {
 	    const unsigned long long k = atomicAdd(counter, 1ull);
 	    if (k < dst_cap)
 		dst[k] = (position << 24) | addr;
@@ -1248,7 +1264,7 @@ filter_kernel(sora_resolve_args a) {
 		    known = (a.known_bits[addr >> 5] >> (addr & 31)) & 1;
 		if (known)
 		    known = (kHashed? seen_lookup_hashed(a, addr) : a.first_seen[addr]) <
-			    a.base_position + pos;
+			    (a.seen_tag | (a.base_position + pos));
 		if (known)
 		    r[u] |= SORA_REC_ACCEPTED << 60;
 		kept = known || a.emit_all;
@@ -1271,8 +1287,10 @@ filter_kernel(sora_resolve_args a) {
 	    n_acc += (uint32_t) __builtin_amdgcn_readlane((int) incl, 63);
 	}
     }
-    if (lane == 0)
+    if (lane == 0) {
 	a.acc_count[region] = n_acc;
+	note_overflow(a.summary, SORA_SUM_ACC_OVER, n_acc, a.acc_cap);
+    }
 }
 
 /* accepted regions -> one flat, position-sorted list */
@@ -1750,18 +1768,18 @@ sora_launch_first_seen(const sora_resolve_args *a, hipStream_t stream) {
 }
 
 hipError_t
-sora_launch_add_known(uint64_t *first_seen, uint32_t *known_bits,
+sora_launch_add_known(uint64_t *first_seen, uint32_t *known_bits, uint64_t seen_tag,
 	const uint64_t *records, uint64_t n, hipStream_t stream) {
     if (n == 0)
 	return hipSuccess;
     (void) hipGetLastError();
     hipLaunchKernelGGL(add_known_kernel, dim3(grid_for(n, 256)), dim3(256), 0,
-	    stream, first_seen, known_bits, records, n);
+	    stream, first_seen, known_bits, seen_tag, records, n);
     return hipGetLastError();
 }
 
 hipError_t
-sora_launch_add_known_blocks(uint64_t *first_seen, uint32_t *known_bits,
+sora_launch_add_known_blocks(uint64_t *first_seen, uint32_t *known_bits, uint64_t seen_tag,
 	const uint64_t *blocks, uint32_t n_blocks, uint32_t stride, uint32_t skip,
 	hipStream_t stream) {
     if (n_blocks == 0 || stride < 2)
@@ -1769,20 +1787,20 @@ sora_launch_add_known_blocks(uint64_t *first_seen, uint32_t *known_bits,
     (void) hipGetLastError();
     hipLaunchKernelGGL(add_known_blocks_kernel, dim3(grid_for(stride - 1, 256) > 16?
 	    16 : grid_for(stride - 1, 256), n_blocks), dim3(256), 0, stream,
-	    first_seen, known_bits, blocks, stride, skip);
+	    first_seen, known_bits, seen_tag, blocks, stride, skip);
     return hipGetLastError();
 }
 
 hipError_t
 sora_launch_scan_counts(const uint32_t *counts, uint32_t cap,
-	uint64_t *offsets, uint32_t n, hipStream_t stream) {
+	uint64_t *offsets, uint32_t n, uint64_t *total, hipStream_t stream) {
     (void) hipGetLastError();
     if (cap < (1u << 26))
 	hipLaunchKernelGGL(scan_counts_kernel<true>, dim3(1), dim3(1024), 0, stream,
-		counts, cap, offsets, n);
+		counts, cap, offsets, n, total);
     else
 	hipLaunchKernelGGL(scan_counts_kernel<false>, dim3(1), dim3(1024), 0, stream,
-		counts, cap, offsets, n);
+		counts, cap, offsets, n, total);
     return hipGetLastError();
 }
 

@@ -220,7 +220,7 @@ sora_adsb_decode_noalloc(int device, void *stream_, const void *d_iq, size_t nby
     NOALLOC_TRY(sora_launch_first_seen(&r, stream));
     NOALLOC_TRY(sora_launch_filter(&r, stream));
     NOALLOC_TRY(sora_launch_scan_counts(r.acc_count, r.acc_cap, r.acc_offset, r.regions,
-	    stream));
+	    nullptr, stream));
     NOALLOC_TRY(sora_launch_finalize(&r, dev.cus, stream));
     NOALLOC_TRY(sora_launch_noalloc_status(&r, cap_frames, d_status, stream));
 #undef NOALLOC_TRY
