@@ -24,6 +24,7 @@ probe(uint32_t *out, uint64_t *cycles, uint32_t seed) {
     uint32_t r[8], a = seed + threadIdx.x, b = seed * 3 + 1, c = 0x00010001u << (threadIdx.x & 15);
     for (int i = 0; i < 8; i++)
 	r[i] = a * (i + 1);
+    asm volatile("s_mov_b64 s[40:41], 0x5555\n\ts_mov_b64 vcc, 0x3333" ::: "s40", "s41", "vcc");
     __builtin_amdgcn_s_barrier();
     const uint64_t t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < kIter; it++) {
@@ -41,7 +42,45 @@ probe(uint32_t *out, uint64_t *cycles, uint32_t seed) {
 #define OP_LSHLOR(i) asm volatile("v_lshl_or_b32 %0, %0, 1, %1" : "+v"(r[i]) : "v"(a));
 #define OP_BFE(i)   asm volatile("v_bfe_u32 %0, %0, 3, 8" : "+v"(r[i]));
 #define OP_ADDDPP(i) asm volatile("v_add_u32_dpp %0, %1, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "+v"(r[i]) : "v"(a));
+#define OP_CMP(i)   asm volatile("v_cmp_lt_u32 vcc, %0, %1" :: "v"(r[i]), "v"(a) : "vcc");
+#define OP_CMPMOV(i) asm volatile("v_cmp_lt_u32 vcc, %0, %1\n\ts_mov_b64 s[40:41], vcc" :: "v"(r[i]), "v"(a) : "vcc", "s40", "s41");
+#define OP_CMPAND(i) asm volatile("v_cmp_lt_u32 vcc, %0, %1\n\ts_and_b64 s[40:41], s[40:41], vcc" :: "v"(r[i]), "v"(a) : "vcc", "s40", "s41", "scc");
+#define OP_CMP64(i) asm volatile("v_cmp_lt_u32_e64 s[40:41], %0, %1" :: "v"(r[i]), "v"(a) : "s40", "s41");
+#define OP_CMPADDC(i) asm volatile("v_cmp_lt_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(r[i]) : "v"(b), "v"(a) : "vcc");
+#define OP_ADDC(i)  asm volatile("v_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(r[i]) :: "vcc");
+#define OP_MAX3(i)  asm volatile("v_max3_u32 %0, %0, %1, %2" : "+v"(r[i]) : "v"(a), "v"(b));
+#define OP_MAX(i)   asm volatile("v_max_u32 %0, %0, %1" : "+v"(r[i]) : "v"(a));
+#define OP_ANDS(i)  asm volatile("v_and_b32 %0, %1, %0" : "+v"(r[i]) : "s"(0xffff0000u));
+#define OP_NOT(i)   asm volatile("v_not_b32 %0, %0" : "+v"(r[i]));
+#define OP_CNDMASK(i) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(r[i]) : "v"(a) : "vcc");
+#define OP_DOT4U(i) asm volatile("v_dot4_u32_u8 %0, %1, %1, %0" : "+v"(r[i]) : "v"(a));
+#define OP_SUB(i)   asm volatile("v_sub_u32 %0, %0, %1" : "+v"(r[i]) : "v"(a));
+#define OP_LSHR(i)  asm volatile("v_lshrrev_b32 %0, 1, %0" : "+v"(r[i]));
+#define OP_CMPSALU4(i) asm volatile("v_cmp_lt_u32 vcc, %0, %1\n\ts_and_b64 s[40:41], s[42:43], vcc\n\ts_andn2_b64 s[44:45], s[40:41], s[46:47]\n\ts_lshr_b64 s[42:43], s[44:45], 1\n\ts_mov_b64 s[46:47], vcc" :: "v"(r[i]), "v"(a) : "vcc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "scc");
+#define OP_CND64(i) asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[40:41]" : "+v"(r[i]) : "v"(a) : "s40", "s41");
+#define OP_CMPCND(i) asm volatile("v_cmp_lt_u32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(r[i]) : "v"(a) : "vcc");
+#define OP_CNDMIX(i) asm volatile("v_cndmask_b32 %0, %0, %1, vcc\n\tv_xor_b32 %0, %0, %1\n\tv_add_u32 %0, %0, %1\n\tv_xor_b32 %0, %0, %1" : "+v"(r[i]) : "v"(a) : "vcc");
+#define OP_CNDK(i) asm volatile("v_cndmask_b32 %0, 0, %1, vcc" : "+v"(r[i]) : "v"(a) : "vcc");
 	if constexpr (kKind == 0) { BODY(OP_ADD) }
+	if constexpr (kKind == 40) { BODY(OP_CND64) }
+	if constexpr (kKind == 41) { BODY(OP_CMPCND) }
+	if constexpr (kKind == 42) { BODY(OP_CNDMIX) }
+	if constexpr (kKind == 43) { BODY(OP_CNDK) }
+	if constexpr (kKind == 20) { BODY(OP_CMP) }
+	if constexpr (kKind == 21) { BODY(OP_CMPMOV) }
+	if constexpr (kKind == 22) { BODY(OP_CMPAND) }
+	if constexpr (kKind == 23) { BODY(OP_CMP64) }
+	if constexpr (kKind == 24) { BODY(OP_CMPADDC) }
+	if constexpr (kKind == 25) { BODY(OP_ADDC) }
+	if constexpr (kKind == 26) { BODY(OP_MAX3) }
+	if constexpr (kKind == 27) { BODY(OP_MAX) }
+	if constexpr (kKind == 28) { BODY(OP_ANDS) }
+	if constexpr (kKind == 29) { BODY(OP_NOT) }
+	if constexpr (kKind == 30) { BODY(OP_CNDMASK) }
+	if constexpr (kKind == 31) { BODY(OP_DOT4U) }
+	if constexpr (kKind == 32) { BODY(OP_SUB) }
+	if constexpr (kKind == 33) { BODY(OP_LSHR) }
+	if constexpr (kKind == 34) { BODY(OP_CMPSALU4) }
 	if constexpr (kKind == 1) { BODY(OP_PKSUB) }
 	if constexpr (kKind == 2) { BODY(OP_PKMAD) }
 	if constexpr (kKind == 3) { BODY(OP_PKMAX) }
@@ -118,5 +157,25 @@ main() {
     run<11>("v_lshl_or_b32", d_out, d_cyc, cus);
     run<12>("v_bfe_u32", d_out, d_cyc, cus);
     run<13>("v_add_u32_dpp", d_out, d_cyc, cus);
+    printf("-- per OP below: the instruction group named (2 = VALU + VALU, +s = with SALU)\n");
+    run<20>("v_cmp e32", d_out, d_cyc, cus);
+    run<21>("v_cmp +s_mov", d_out, d_cyc, cus);
+    run<22>("v_cmp +s_and", d_out, d_cyc, cus);
+    run<34>("v_cmp +4 salu", d_out, d_cyc, cus);
+    run<23>("v_cmp e64 sgpr", d_out, d_cyc, cus);
+    run<24>("v_cmp,v_addc 2", d_out, d_cyc, cus);
+    run<25>("v_addc e32", d_out, d_cyc, cus);
+    run<26>("v_max3_u32", d_out, d_cyc, cus);
+    run<27>("v_max_u32", d_out, d_cyc, cus);
+    run<28>("v_and_b32 s,v", d_out, d_cyc, cus);
+    run<29>("v_not_b32", d_out, d_cyc, cus);
+    run<30>("v_cndmask e32", d_out, d_cyc, cus);
+    run<40>("v_cndmask e64 s", d_out, d_cyc, cus);
+    run<41>("v_cmp,v_cndmask2", d_out, d_cyc, cus);
+    run<42>("cndmask+3 fast 4", d_out, d_cyc, cus);
+    run<43>("v_cndmask 0,v", d_out, d_cyc, cus);
+    run<31>("v_dot4_u32_u8", d_out, d_cyc, cus);
+    run<32>("v_sub_u32", d_out, d_cyc, cus);
+    run<33>("v_lshrrev_b32", d_out, d_cyc, cus);
     return 0;
 }
