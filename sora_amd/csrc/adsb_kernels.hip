@@ -44,6 +44,7 @@
 #include "adsb_tile.h"
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
@@ -586,13 +587,30 @@ next_lane(uint32_t v) {
 }
 
 /*
- * Waves per SIMD (= workgroups per CU) of the direct kernel: the sixteen
- * registers that hold the next tile's samples while this tile is worked on
- * (see the tile loop) take the kernel from 71 to about 90 VGPRs.
+ * Waves per SIMD (= workgroups per CU) of the direct kernel.  Registers would
+ * allow five (92 VGPRs with the next tile's samples held while a tile is worked
+ * on); the LDS ring that collects the candidate records (below) allows four.
+ * Three to seven all run the 1-hour capture within 2 % of each other.
  */
 #ifndef SORA_DIRECT_WAVES
 #define SORA_DIRECT_WAVES 5
 #endif
+/*
+ * Candidate records leave the workgroup 1024 at a time.  Measured on this GPU
+ * (tools/probe/stream_mix_probe.cpp): beside a streaming read at full rate, a
+ * thin stream of stores costs far more than its bytes -- two 6-byte records per
+ * tile and workgroup (11 MB in all) slow the 14.4 GB read by 0.44 ms, the 169 a
+ * tile has on average by 0.87 ms, wherever they go (own regions, interleaved
+ * blocks, lines that stay in L2), whatever their width or cache policy, and
+ * although nothing waits for them; the same bytes written every sixth tile cost
+ * 0.68 ms, every sixteenth 0.59.  So phase 4 puts a record into a ring in LDS
+ * (slot modulo 2048), and once a tile has completed a run of 1024 slots the
+ * whole workgroup writes that run with one 16-byte store of keys and one
+ * 8-byte store of tails per thread.
+ */
+constexpr uint32_t kStageUnit = 1024;		/* records per flush: four per thread */
+constexpr uint32_t kStageRing = 2 * kStageUnit;	/* a unit being filled behind one being written */
+constexpr uint32_t kStagePass = 512;		/* records staged between two flushes, at most */
 constexpr int kSqLds = 128;		/* clean squitters a workgroup keeps in LDS */
 
 template <int kThreads>
@@ -601,7 +619,9 @@ adsb_scan_direct_kernel(sora_scan_args a) {
     using D = direct_geom<kThreads>;
     constexpr int kWaves = D::waves;
     constexpr int kTilePos = D::tile_pos;
-    constexpr int kQueueMax = kTilePos / 2;		/* p and p+1 never both hit */
+    /* the hit queue holds kQueueCap candidates; a tile with more (p and p + 1
+     * never both hit: up to kTilePos / 2) is worked off in windows of that many */
+    constexpr uint32_t kQueueCap = 2 * kStagePass;
     constexpr int kWords = (D::lanes + 2) / 2 + 1;
     constexpr int kTabWords = SORA_CRC_TABLE_WORDS + SORA_FIX_TABLE_WORDS;
 
@@ -609,7 +629,7 @@ adsb_scan_direct_kernel(sora_scan_args a) {
      * read as 32-bit words */
     __shared__ __attribute__((aligned(4))) uint16_t s_bits[2][2][2 * kWords];
     __shared__ __attribute__((aligned(16))) uint32_t s_tab[kTabWords];
-    __shared__ uint16_t s_queue[kQueueMax];
+    __shared__ uint16_t s_queue[kQueueCap];
     __shared__ uint32_t s_cum[2][kWaves + 1];	/* by tile parity, see below */
     __shared__ uint32_t s_sq_total;
     /* the workgroup's clean squitters (about sixty per range of the 1-hour
@@ -617,6 +637,9 @@ adsb_scan_direct_kernel(sora_scan_args a) {
      * tile loop issues no store that only some tiles have (see the tile loop);
      * those beyond kSqLds go straight to the global list */
     __shared__ uint64_t s_sq[kSqLds];
+    /* the records on their way out: slot n of the region at n mod kStageRing */
+    __shared__ __attribute__((aligned(16))) uint32_t s_stage_key[kStageRing];
+    __shared__ __attribute__((aligned(16))) uint16_t s_stage_tail[kStageRing];
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63, wave = tid >> 6;
@@ -626,7 +649,8 @@ adsb_scan_direct_kernel(sora_scan_args a) {
     const uint64_t tile_end = a.n_tiles * (group + 1) / groups;
 
     uint64_t *sq_out = a.sq + (uint64_t) group * a.sq_cap;
-    uint32_t n_rec = 0;
+    uint32_t n_rec = 0;		/* records so far (counted on past the region's end) */
+    uint32_t n_flushed = 0;	/* ... of which written out: a multiple of kStageUnit */
     uint32_t st_cand = 0, st_sq = 0, st_dirty = 0, st_fixed = 0;
 
     /* The record region of this workgroup as two buffers: a store beyond the
@@ -664,12 +688,30 @@ adsb_scan_direct_kernel(sora_scan_args a) {
 	for (int r = 0; r < 4; r++)
 	    v[r] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, g * 64, r * 16, 0);
     };
-    /* a record's key and tail at slot idx of the region; idx = ~0: none */
-    auto store_record = [&](uint32_t idx, uint32_t key, uint32_t tail) {
-	const uint32_t none = idx == 0xffffffffu;
-	__builtin_amdgcn_raw_buffer_store_b32(key, rsrc_key, none? 0xffffffffu : idx * 4, 0, 0);
-	__builtin_amdgcn_raw_buffer_store_b16((uint16_t) tail, rsrc_tail,
-		none? 0xffffffffu : idx * 2, 0, 0);
+    /* a record's key and tail for slot idx of the region, into the ring (what
+     * does not fit the region is counted, not kept) */
+    auto stage_record = [&](uint32_t idx, uint32_t key, uint32_t tail) {
+	if (idx < a.rec_cap) {
+	    s_stage_key[idx & (kStageRing - 1)] = key;
+	    s_stage_tail[idx & (kStageRing - 1)] = (uint16_t) tail;
+	}
+    };
+    /* Slots [n_flushed, n_flushed + kStageUnit) out of the ring into the region:
+     * thread t takes four, a 16-byte store of keys and an 8-byte store of tails
+     * (kStageUnit = 4 * kThreads; the region's capacity is a multiple of 8, so
+     * the bounds check drops whole stores).  `live` false: the same two stores
+     * with an offset out of range -- every pass of the tile loop issues them. */
+    static_assert(kStageUnit == 4 * kThreads, "one flush = four records per thread");
+    auto flush_unit = [&](uint32_t t, bool live) {
+	u32x4 k4 = {0, 0, 0, 0};
+	u32x2 t2 = {0, 0};
+	const uint32_t first = n_flushed + 4 * t;
+	if (live) {
+	    k4 = *reinterpret_cast<const u32x4 *>(&s_stage_key[first & (kStageRing - 1)]);
+	    t2 = *reinterpret_cast<const u32x2 *>(&s_stage_tail[first & (kStageRing - 1)]);
+	}
+	__builtin_amdgcn_raw_buffer_store_b128(k4, rsrc_key, live? first * 4 : 0xffffffffu, 0, 0);
+	__builtin_amdgcn_raw_buffer_store_b64(t2, rsrc_tail, live? first * 2 : 0xffffffffu, 0, 0);
     };
 
     /*
@@ -686,16 +728,16 @@ adsb_scan_direct_kernel(sora_scan_args a) {
      * time: for that wait not to include the record stores of phase 4 -- which
      * come AFTER the loads -- every pass through the loop must issue the SAME
      * operations: four loads and two stores, whatever the tile holds.  Hence
-     * loads on an empty buffer behind the last tile, stores with an
-     * out-of-range offset for lanes without a record, the squitter list in
-     * LDS, and two dropped stores in front of the loop so that the first pass
-     * finds what every other pass finds.  (A tile with more than kThreads
-     * candidates takes extra passes with stores of their own: more operations
-     * behind the loads only make the wait conservative.)
+     * loads on an empty buffer behind the last tile, the record flush with an
+     * out-of-range offset on the passes that have no full unit to write, the
+     * squitter list in LDS, and two dropped stores in front of the loop so that
+     * the first pass finds what every other pass finds.  (A tile with more than
+     * kStagePass candidates flushes between its parts: more operations behind
+     * the loads only make the wait conservative.)
      */
     u32x4 v[4];
     load_run(v, tile_begin, 63 * wave + lane, tile_begin < tile_end);
-    store_record(0xffffffffu, 0, 0);
+    flush_unit(tid, false);
     STAMP_DECL;
 
     for (uint64_t tile = tile_begin; tile < tile_end; tile++) {
@@ -781,32 +823,27 @@ adsb_scan_direct_kernel(sora_scan_args a) {
 	STAMP(3);			/* predicate, hit count, wave prefix */
 	lds_barrier();			/* A: every wave is done with the previous tile */
 	STAMP(4);			/* barrier A */
-	const uint32_t total = s_cum[par][kWaves];
+	const uint32_t total = (uint32_t) __builtin_amdgcn_readfirstlane((int) s_cum[par][kWaves]);
 	uint32_t off = s_cum[par][w] + incl - cnt;
+	/* the records of the tiles before this one are in the ring (every wave has
+	 * left their phase 4): a full unit among them goes out now */
+	{
+	    const bool ready = n_rec - n_flushed >= kStageUnit;
+	    flush_unit(t, ready);
+	    if (ready)
+		n_flushed += kStageUnit;
+	}
 	/* the other parity's prefix is used next by the following tile's atomics,
 	 * which no wave reaches before barrier B */
 	if (t <= (uint32_t) kWaves)
 	    s_cum[par ^ 1][t] = 0;
-	{
-	    uint32_t both = pe | po;
-	    while (both != 0) {
-		const uint32_t b = __clz(both);
-		const uint32_t twice = __builtin_amdgcn_alignbit(b, po << b, 31);
-		s_queue[off++] = (uint16_t) (g * SORA_LANE_POS | twice);
-		both &= ~(0x80000000u >> b);
-	    }
-	}
-	STAMP(5);			/* queue */
-	lds_barrier();			/* B */
-	STAMP(6);			/* barrier B */
-
 	/* ---- phase 4: one lane per candidate (as adsb_scan_kernel) ---- */
 	const uint32_t *w_nue = reinterpret_cast<const uint32_t *>(s_nue);
 	const uint32_t *w_nuo = reinterpret_cast<const uint32_t *>(s_nuo);
 	st_cand += total;
-	/* candidate i of the tile: its record (slot n_rec + i) and statistics */
-	auto candidate = [&](uint32_t i, uint32_t *key, uint32_t *tail) {
-	    uint32_t q = s_queue[i];
+	/* queue entry j: its record (key and tail) and statistics */
+	auto candidate = [&](uint32_t j, uint32_t *key, uint32_t *tail) {
+	    uint32_t q = s_queue[j];
 	    const uint32_t *words = (q & 1)? w_nuo : w_nue;
 	    uint32_t bits[4];
 	    sora_candidate c;
@@ -843,21 +880,56 @@ adsb_scan_direct_kernel(sora_scan_args a) {
 	    if (a.correct)
 		st_fixed += (uint32_t) __popcll(__ballot(kind == SORA_REC_KIND_CORRECTED));
 	};
-	/* the rare passes first (a tile with more than kThreads candidates), the
-	 * pass every tile has last: its two stores are the loop's youngest */
-	for (uint32_t base = kThreads; base < total; base += kThreads) {
-	    const uint32_t i = base + t;
-	    if (i < total) {
-		uint32_t key, tail;
-		candidate(i, &key, &tail);
-		store_record(n_rec + i, key, tail);
+	/* Candidates [win, win + kQueueCap) of the tile at a time: nearly always
+	 * all of them (a tile has about 170), so this loop is one pass -- queue,
+	 * barrier B, candidates -- and the barriers at its end belong to dense
+	 * tiles alone.  (Measured and left out: rotating, from tile to tile, which
+	 * wave takes the first 64 candidates, since waves 0 and 1 always work
+	 * through phase 4 and wave 3 never does: no change.) */
+	for (uint32_t win = 0; ; ) {
+	    {
+		uint32_t both = pe | po, at = off - win;	/* wraps below the window */
+		while (both != 0) {
+		    const uint32_t b = __clz(both);
+		    const uint32_t twice = __builtin_amdgcn_alignbit(b, po << b, 31);
+		    if (at < kQueueCap)
+			s_queue[at] = (uint16_t) (g * SORA_LANE_POS | twice);
+		    at++;
+		    both &= ~(0x80000000u >> b);
+		}
 	    }
-	}
-	{
-	    uint32_t key = 0, tail = 0;
-	    if (t < total)
-		candidate(t, &key, &tail);
-	    store_record(t < total? n_rec + t : 0xffffffffu, key, tail);
+	    STAMP(5);			/* queue */
+	    lds_barrier();		/* B */
+	    STAMP(6);			/* barrier B */
+	    const uint32_t stop = total - win < kQueueCap? total : win + kQueueCap;
+	    if (stop - win <= kStagePass) {
+		/* the common case (and up to three times it): no barrier, no store */
+		for (uint32_t i = win + t; i < stop; i += kThreads) {
+		    uint32_t key, tail;
+		    candidate(i - win, &key, &tail);
+		    stage_record(n_rec + i, key, tail);
+		}
+	    } else {
+		/* kStagePass candidates at a time, and a unit out of the ring
+		 * whenever one is full (the ring holds two) */
+		for (uint32_t first = win; first < stop; first += kStagePass) {
+		    const uint32_t last = stop - first < kStagePass? stop : first + kStagePass;
+		    for (uint32_t i = first + t; i < last; i += kThreads) {
+			uint32_t key, tail;
+			candidate(i - win, &key, &tail);
+			stage_record(n_rec + i, key, tail);
+		    }
+		    lds_barrier();
+		    const bool ready = n_rec + last - n_flushed >= kStageUnit;
+		    flush_unit(t, ready);
+		    if (ready)
+			n_flushed += kStageUnit;
+		}
+	    }
+	    win += kQueueCap;
+	    if (win >= total)
+		break;
+	    lds_barrier();		/* the queue is read; the next window fills it */
 	}
 	n_rec += total;
 	STAMP(7);			/* candidates */
@@ -865,7 +937,17 @@ adsb_scan_direct_kernel(sora_scan_args a) {
 	 * writes come behind its barrier A */
     }
 
-    lds_barrier();			/* the last tile's squitter appends */
+    lds_barrier();			/* the last tile's records and squitter appends */
+    {
+	/* what is left in the ring: fewer than kStageUnit + kStagePass records */
+	uint32_t *key_out = a.key + (uint64_t) group * a.rec_cap;
+	uint16_t *tail_out = a.tail + (uint64_t) group * a.rec_cap;
+	const uint32_t end = n_rec < a.rec_cap? n_rec : a.rec_cap;
+	for (uint32_t i = n_flushed + tid; i < end; i += kThreads) {
+	    key_out[i] = s_stage_key[i & (kStageRing - 1)];
+	    tail_out[i] = s_stage_tail[i & (kStageRing - 1)];
+	}
+    }
     const uint32_t n_sq = s_sq_total;
     if (tid == 0) {
 	a.rec_count[group] = n_rec;

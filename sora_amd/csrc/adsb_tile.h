@@ -236,28 +236,6 @@ sora_pk_sub_i16_sat(uint32_t a, uint32_t b) {
 #endif
 }
 
-/*
- * per half: the sign of w as a bit pattern -- 0x8000 if w > 0, 0x7fff if
- * w < 0, 0 if w == 0: w * -32768 saturated to 16 bits (v_pk_mad_i16 ... clamp).
- * Bits 0..14 say "negative", bit 15 says "positive"; applied twice it swaps
- * the two.
- */
-SORA_HD uint32_t
-sora_pk_sign_pattern(uint32_t w) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    uint32_t r;
-    asm("v_pk_mad_i16 %0, %1, %2, 0 clamp" : "=v"(r) : "v"(w), "s"(0x80008000u));
-    return r;
-#else
-    uint32_t r = 0;
-    for (int h = 0; h < 2; h++) {
-	const int32_t x = (int16_t) (w >> (16 * h));
-	r |= (x > 0? 0x8000u : x < 0? 0x7fffu : 0u) << (16 * h);
-    }
-    return r;
-#endif
-}
-
 /* per half, signed maximum (v_pk_max_i16) */
 SORA_HD uint32_t
 sora_pk_max_i16(uint32_t a, uint32_t b) {
@@ -298,6 +276,32 @@ sora_pair_shift(uint32_t p, uint32_t pn) {
 #endif
 }
 
+/*
+ * The signs of four halves as four bytes: byte 0/1 = 0xff iff the low/high
+ * half of a is negative, byte 2/3 the same for b.  One v_perm_b32: its byte
+ * selectors 8..11 stand for "bit 7 of byte 1, 3, 5, 7 of {S0:S1}, replicated".
+ */
+SORA_HD uint32_t
+sora_sign_bytes(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_perm(b, a, 0x0b0a0908u);
+#else
+    return ((a & 0x8000u)? 0xffu : 0u) | ((a & 0x80000000u)? 0xff00u : 0u) |
+	    ((b & 0x8000u)? 0xff0000u : 0u) | ((b & 0x80000000u)? 0xff000000u : 0u);
+#endif
+}
+
+/* bytes (b3, b2, b1, b0) -> halves (b1:b3, b0:b2): see sora_lane_compare */
+SORA_HD uint32_t
+sora_flag_bytes_to_halves(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_perm(v, v, 0x01030002u);
+#else
+    return ((v >> 16) & 0xffu) | ((v & 0xffu) << 8) | ((v >> 24) << 16) |
+	    (((v >> 8) & 0xffu) << 24);
+#endif
+}
+
 /* ---- a3/a5 on one lane's run of 16 pairs ---- */
 
 /*
@@ -307,22 +311,28 @@ sora_pair_shift(uint32_t p, uint32_t pn) {
  *   up   M[i+1] >  M[i]		(NU = ~up is the slicer bit, plane-iq.c:65)
  *   down M[i+1] <  M[i]
  *   c    M[i] > max(M[i+4], M[i+5], M[i+6])
- * One saturating difference w = M'[i+1] - M'[i] serves up and down: its sign
- * pattern x has "down" in bits 0..14 and "up" in bit 15, the pattern of x the
- * other way round, and v_and_or_b32 picks the pair's bit out of whichever has
- * it.  Per pair: the shifted pair, two maxima, 5 instructions for up and down,
- * 3 for c: 11 VALU instructions for both parities.
+ * Each is the sign of a saturating difference (v_pk_sub_i16 clamp: the exact
+ * difference of two M' can be +32768).  The signs are collected four at a time:
+ * sora_sign_bytes turns the differences of pairs m and m + 8 into four bytes of
+ * 0x00 / 0xff, v_and_or_b32 with 0x01010101 << (7 - m) keeps bit 7 - m of each,
+ * so that after m = 0..7 byte 0 holds the even positions of pairs 0..7, MSB
+ * first, byte 1 their odd positions, bytes 2 and 3 the same for pairs 8..15; one
+ * more v_perm_b32 puts the bytes in half-word order.  Per lane run: 18 shifted
+ * pairs, 32 maxima, 48 differences, 24 + 24 + 3 to collect them: 149 VALU
+ * instructions, 9.3 per pair (11 until round 2, when every difference went
+ * through a sign pattern, v_pk_mad_i16 clamp, and every pair through a
+ * v_and_or_b32 of its own per bit set).
  */
 SORA_HD void
 sora_lane_compare(const uint32_t *P, uint32_t *up, uint32_t *down, uint32_t *c) {
-    uint32_t S[SORA_LANE_PAIRS + 3];
+    uint32_t S[SORA_LANE_PAIRS + 2];
     uint32_t W[SORA_LANE_PAIRS + 2];
     uint32_t acc_u = 0, acc_d = 0, acc_c = 0;
 
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-    for (int s = 0; s < SORA_LANE_PAIRS + 3; s++)
+    for (int s = 0; s < SORA_LANE_PAIRS + 2; s++)
 	S[s] = sora_pair_shift(P[s], P[s + 1]);
     /* W[s] = [max M'[2s..2s+2], max M'[2s+1..2s+3]] */
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -333,26 +343,20 @@ sora_lane_compare(const uint32_t *P, uint32_t *up, uint32_t *down, uint32_t *c) 
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-    for (int s = 0; s < SORA_LANE_PAIRS; s++) {
-	const uint32_t mask = 0x00010001u << (15 - s);
-	const uint32_t x = sora_pk_sign_pattern(sora_pk_sub_i16_sat(S[s], P[s]));
-	const uint32_t y = sora_pk_sign_pattern(x);
+    for (int m = 0; m < SORA_LANE_PAIRS / 2; m++) {
+	const int n = m + SORA_LANE_PAIRS / 2;
+	const uint32_t keep = 0x01010101u << (7 - m);
 
-	if (s == 0) {		/* bit 15: "positive" of x is up, of y is down */
-	    acc_u = sora_and_or(x, mask, acc_u);
-	    acc_d = sora_and_or(y, mask, acc_d);
-	    acc_c = sora_and_or(sora_pk_sign_pattern(sora_pk_sub_i16_sat(P[s], W[s + 2])),
-		    mask, acc_c);
-	} else {		/* bits 0..14: "negative" of x is down, of y is up */
-	    acc_d = sora_and_or(x, mask, acc_d);
-	    acc_u = sora_and_or(y, mask, acc_u);
-	    acc_c = sora_and_or(sora_pk_sign_pattern(sora_pk_sub_i16_sat(W[s + 2], P[s])),
-		    mask, acc_c);
-	}
+	acc_d = sora_and_or(sora_sign_bytes(sora_pk_sub_i16_sat(S[m], P[m]),
+		sora_pk_sub_i16_sat(S[n], P[n])), keep, acc_d);
+	acc_u = sora_and_or(sora_sign_bytes(sora_pk_sub_i16_sat(P[m], S[m]),
+		sora_pk_sub_i16_sat(P[n], S[n])), keep, acc_u);
+	acc_c = sora_and_or(sora_sign_bytes(sora_pk_sub_i16_sat(W[m + 2], P[m]),
+		sora_pk_sub_i16_sat(W[n + 2], P[n])), keep, acc_c);
     }
-    *up = acc_u;
-    *down = acc_d;
-    *c = acc_c;
+    *up = sora_flag_bytes_to_halves(acc_u);
+    *down = sora_flag_bytes_to_halves(acc_d);
+    *c = sora_flag_bytes_to_halves(acc_c);
 }
 
 /* (acc << 1) | (the sign of d): one v_alignbit_b32 */
