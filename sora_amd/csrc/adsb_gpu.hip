@@ -119,7 +119,7 @@ void stream_release(sora_adsb_ctx *ctx);
 	    return fail((ctx), SORA_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_)); \
     } while (0)
 
-constexpr uint32_t kScanRounds = 16;	/* rounds of scan workgroups per CU */
+constexpr uint32_t kScanRounds = 32;	/* rounds of scan workgroups per CU */
 constexpr uint64_t kSummaryAlloc = 32;	/* words behind d_summary: zeroed 256 bytes at a time */
 constexpr uint32_t kMinTiles = 8;	/* tiles per workgroup, at least */
 
@@ -360,13 +360,14 @@ sora_adsb_create(sora_adsb_ctx **out, int device, const sora_adsb_config *cfg) {
     /* the scan kernels run sora_scan_groups_per_cu() workgroups on every CU
      * (what their LDS lets a CU hold): at most 4 */
     ctx->cus = prop.multiProcessorCount > 0? (uint32_t) prop.multiProcessorCount : 1;
-    /* ... in kScanRounds rounds: a workgroup takes a range of tiles a sixteenth
-     * of what a resident one would, so CUs that run ahead (clock, HBM channel
-     * luck) take more ranges instead of waiting for the slowest: measured 3.67
-     * -> 3.39 ms on the 1-hour capture, flat from 16 to 24 rounds.  A range is at
-     * least kMinTiles tiles (the CRC tables are loaded into LDS once per range).
-     * SORA_ADSB_SCAN_ROUNDS / SORA_ADSB_SCAN_MIN_TILES override both (tuning and
-     * tests). */
+    /* ... in kScanRounds rounds: a workgroup takes a short range of tiles, so
+     * CUs that run ahead (clock, HBM channel luck) take more ranges instead of
+     * waiting for the slowest: measured 3.67 -> 3.39 ms on the 1-hour capture
+     * from 1 round to 16 in round 1, and with the LDS record ring of round 2
+     * 3.80 / 3.73 / 3.68 / 3.66 / 3.66 ms per step at 6 / 12 / 16 / 32 / 48
+     * rounds.  A range is at least kMinTiles tiles (the CRC tables are loaded
+     * into LDS once per range).  SORA_ADSB_SCAN_ROUNDS / SORA_ADSB_SCAN_MIN_TILES
+     * override both (tuning and tests). */
     ctx->scan_variant = env_number("SORA_ADSB_SCAN_VARIANT", 1, 0, 1);
     ctx->scan_rounds = env_number("SORA_ADSB_SCAN_ROUNDS", kScanRounds, 1, 64);
     ctx->scan_min_tiles = env_number("SORA_ADSB_SCAN_MIN_TILES", kMinTiles, 1, 1 << 20);
