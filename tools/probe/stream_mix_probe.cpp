@@ -234,17 +234,34 @@ run(const uint8_t *d, uint64_t bytes, uint32_t *key, uint16_t *tail, uint32_t re
 }
 
 int
-main() {
+main(int argc, char **argv) {
     const uint64_t bytes = 14400000000ull;
     const uint32_t rec_cap = 16384;
+    // argv[1]: how the record arrays are allocated: 0 hipMalloc, 1 uncached, 2 fine-grained
+    const int kind = argc > 1? atoi(argv[1]) : 0;
     uint8_t *d;
     uint32_t *d_out, *key;
     uint16_t *tail;
     CHECK(hipMalloc(&d, bytes));
     CHECK(hipMalloc(&d_out, 1 << 20));
-    CHECK(hipMalloc(&key, (size_t) 256 * 5 * 16 * rec_cap * 4));
-    CHECK(hipMalloc(&tail, (size_t) 256 * 5 * 16 * rec_cap * 2));
+    const size_t kb = (size_t) 256 * 5 * 16 * rec_cap * 4;
+    if (kind == 0) {
+	CHECK(hipMalloc(&key, kb));
+	CHECK(hipMalloc(&tail, kb / 2));
+    } else {
+	const unsigned flags = kind == 1? hipDeviceMallocUncached : hipDeviceMallocFinegrained;
+	CHECK(hipExtMallocWithFlags((void **) &key, kb, flags));
+	CHECK(hipExtMallocWithFlags((void **) &tail, kb / 2, flags));
+	printf("record arrays: %s\n", kind == 1? "uncached" : "fine-grained");
+    }
     CHECK(hipMemset(d, 1, bytes));
+    run<320, 2, 0>(d, bytes, key, tail, rec_cap, d_out);
+    run<320, 2, 2>(d, bytes, key, tail, rec_cap, d_out);
+    run<320, 2, 169>(d, bytes, key, tail, rec_cap, d_out);
+    run<400, 2, 169>(d, bytes, key, tail, rec_cap, d_out);
+    run<320, 2, 169, 106, 0>(d, bytes, key, tail, rec_cap, d_out);
+    if (kind != 0)
+	return 0;
     run<0, 0, 0>(d, bytes, key, tail, rec_cap, d_out);
     run<200, 0, 0>(d, bytes, key, tail, rec_cap, d_out);
     run<320, 0, 0>(d, bytes, key, tail, rec_cap, d_out);
