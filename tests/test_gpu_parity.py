@@ -730,6 +730,43 @@ def test_more_hits_than_the_small_queue():
     assert_same_frames(got, ob.scan(raw2))
 
 
+def densest_candidates(n):
+    """A period-7 pattern, a preamble hit at every seventh position (the predicate
+    looks six positions ahead of a hit for something smaller): 1115 candidates per
+    7808-position tile of the default scan kernel, more than its hit queue (1024)
+    and more than two flush units of its record ring hold."""
+    v = np.array([9, 1, 8, 1, 2, 2, 2], dtype=np.int64)
+    iq = np.full(2 * n, 128, dtype=np.uint8)
+    iq[0::2] = 128 + 10 * v[np.arange(n) % 7]
+    return iq.tobytes()
+
+
+def test_more_hits_than_the_hit_queue_and_the_record_ring():
+    """Tiles whose candidates are worked off in two windows of the hit queue, the
+    records leaving through the LDS ring in between, next to sparse tiles; with a
+    record list that holds them and with one that is grown (regions that overflow
+    in the middle of a flush unit)."""
+    raw = densest_candidates(5 * 7808 + 500)
+    want = ob.scan(raw)
+    assert len(want) > 5 * 1100
+    got, counts = gpu_frames(raw)
+    assert_same_frames(got, want)
+    assert counts["candidates"] == len(want)
+    rng = np.random.default_rng(14)
+    raw2 = (rng.integers(0, 256, 2 * 30000, dtype=np.uint8).tobytes() + raw +
+            rng.integers(0, 256, 2 * 50000, dtype=np.uint8).tobytes() +
+            dense_candidates(20000))
+    want2 = ob.scan(raw2)
+    got, _ = gpu_frames(raw2)
+    assert_same_frames(got, want2)
+    n = len(raw2) // 2
+    with AdsbContext(n, emit_mode=EMIT_CANDIDATES, max_candidates=4096, max_frames=4096) as ctx:
+        ctx.submit_host(raw2, ENC_UC8)
+        frames = frames_as_dicts(ctx.collect())
+        assert ctx.list_regrows() >= 1
+    assert_same_frames(frames, want2)
+
+
 @pytest.mark.parametrize("min_tiles,rounds", [(1, 16), (3, 1), (8, 2)])
 def test_workgroup_ranges_do_not_matter(monkeypatch, min_tiles, rounds):
     """The scan hands tile ranges to workgroups (at least SORA_ADSB_SCAN_MIN_TILES
