@@ -36,6 +36,8 @@ struct sora_adsb_ctx {
     uint32_t *d_known_bits;
     uint64_t *d_acc_offset, *d_sq_offset;
     uint32_t *d_rec_count, *d_sq_count, *d_acc_count;
+    uint32_t *d_tile_end;	/* sora_scan_args::tile_end: one word per tile of a chunk */
+    uint64_t tile_slots;
     sora_adsb_frame *d_frames;
     uint8_t *d_stage;
     size_t stage_bytes;
@@ -153,7 +155,7 @@ dev_alloc(T **p, uint64_t n) {
 
 /*
  * The lists whose sizes depend on the traffic: candidate records (8 bytes per
- * slot for the 6 used: room for the alignment of the tails and for the
+ * slot for the 5 used: room for the alignment of the tails and for the
  * filter's 16-byte loads past a short region), clean squitters, accepted
  * records (per region and flat) and frames.  Allocated by sora_adsb_create()
  * from the configuration and again, larger, when a scan overflowed them.
@@ -181,15 +183,17 @@ bind_lists(sora_adsb_ctx *ctx) {
 	return (uint32_t) (each > 0x7fffffffull? 0x7fffffffull : each);
     };
 
-    /* the record buffer holds the 4-byte keys, then the 2-byte tails */
+    /* the record buffer holds the 4-byte keys, then the 1-byte tails */
     a.key = reinterpret_cast<uint32_t *>(ctx->d_rec);
-    a.tail = reinterpret_cast<uint16_t *>(reinterpret_cast<uint32_t *>(ctx->d_rec) +
+    a.tail = reinterpret_cast<uint8_t *>(reinterpret_cast<uint32_t *>(ctx->d_rec) +
 	    ctx->rec_total);			/* rec_total is a multiple of 8 */
+    a.tile_end = ctx->d_tile_end;
     a.sq = ctx->d_sq;
     a.rec_cap = share(ctx->rec_total, groups) & ~7u;	/* >= 8: sora_adsb_scan */
     a.sq_cap = share(ctx->sq_total, groups);
     r.key = a.key;
     r.tail = a.tail;
+    r.tile_end = a.tile_end;
     r.rec_cap = a.rec_cap;
     r.sq = ctx->d_sq;
     r.sq_cap = a.sq_cap;
@@ -268,6 +272,7 @@ sora_adsb_destroy(sora_adsb_ctx *ctx) {
     (void) hipFree(ctx->d_rec_count);
     (void) hipFree(ctx->d_sq_count);
     (void) hipFree(ctx->d_acc_count);
+    (void) hipFree(ctx->d_tile_end);
     (void) hipFree(ctx->d_stage);
     (void) hipFree(ctx->d_summary);
     if (ctx->h_summary != nullptr)
@@ -386,6 +391,8 @@ sora_adsb_create(sora_adsb_ctx **out, int device, const sora_adsb_config *cfg) {
 
     const uint32_t g = ctx->max_groups;
     const uint32_t nr = ctx->max_regions;
+    /* no scan kernel's tile has fewer than 7808 positions */
+    ctx->tile_slots = n / 7808 + 16;
     if (alloc_lists(ctx) != hipSuccess ||
 	    dev_alloc(&ctx->d_known_bits, SORA_KNOWN_WORDS) != hipSuccess ||
 	    dev_alloc(&ctx->d_first_seen, SORA_ADDRESSES) != hipSuccess ||
@@ -396,6 +403,7 @@ sora_adsb_create(sora_adsb_ctx **out, int device, const sora_adsb_config *cfg) {
 	    dev_alloc(&ctx->d_rec_count, g) != hipSuccess ||
 	    dev_alloc(&ctx->d_sq_count, g) != hipSuccess ||
 	    dev_alloc(&ctx->d_acc_count, nr) != hipSuccess ||
+	    dev_alloc(&ctx->d_tile_end, ctx->tile_slots) != hipSuccess ||
 	    dev_alloc(&ctx->d_summary, kSummaryAlloc) != hipSuccess)
 	return fail(ctx, SORA_ERR_NOMEM, "hipMalloc of the device lists failed");
     HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_summary),
@@ -443,6 +451,10 @@ sora_adsb_scan(sora_adsb_ctx *ctx, const void *d_iq, size_t nbytes, int encoding
     uint32_t groups = ctx->cus * sora_scan_groups_per_cu(encoding, (int) ctx->scan_variant) * ctx->scan_rounds;
     if (n_tiles / ctx->scan_min_tiles < groups)
 	groups = n_tiles >= ctx->scan_min_tiles? (uint32_t) (n_tiles / ctx->scan_min_tiles) : 1;
+
+    if (n_tiles > ctx->tile_slots)
+	return fail(ctx, SORA_ERR_INVALID, "%llu tiles for %llu slots", (unsigned long long) n_tiles,
+		(unsigned long long) ctx->tile_slots);
 
     /* the filter loads eight records at a time, aligned: a region holds at
      * least eight (few, long regions when the record list is tiny) */

@@ -38,12 +38,15 @@ struct sora_scan_args {
     int32_t correct;		/* SORA_OPT_CORRECT_SINGLE_BIT */
     int32_t pad_;
     /* candidate records, one per candidate in position order, in two arrays
-     * (6 bytes instead of the 8 of a full record: the scan writes and the
+     * (5 bytes instead of the 8 of a full record: the scan writes and the
      * filter reads them all): key = payload[23:0] | kind[25:24] |
-     * region position[21:16] << 26, tail = region position[15:0]; the region
-     * position counts from the first position of the workgroup's tile range */
+     * tile position[13:8] << 26, tail = tile position[7:0]; the tile position
+     * counts from the first position of the candidate's tile (< 2^14 in every
+     * scan kernel).  Which tile: tile_end[t], for every tile t of the chunk, is
+     * the number of records of t's workgroup range up to and including t */
     uint32_t *key;		/* [groups][rec_cap] */
-    uint16_t *tail;		/* [groups][rec_cap] */
+    uint8_t *tail;		/* [groups][rec_cap] */
+    uint32_t *tile_end;		/* [n_tiles] */
     uint64_t *sq;		/* [groups][sq_cap] clean squitters */
     uint32_t rec_cap, sq_cap;	/* per-group capacities */
     uint32_t *rec_count;	/* [groups] records produced (may exceed cap) */
@@ -70,7 +73,8 @@ struct sora_resolve_args {
     int32_t emit_all;
     uint32_t groups;
     const uint32_t *key;	/* scan output, see sora_scan_args */
-    const uint16_t *tail;
+    const uint8_t *tail;
+    const uint32_t *tile_end;
     uint64_t n_tiles;		/* of the scan: region g starts at tile n_tiles * g / groups */
     uint32_t tile_pos;		/* positions per tile of the scan kernel that ran */
     const uint32_t *rec_count;
@@ -122,7 +126,8 @@ struct sora_resolve_args {
 #define SORA_SUM_FRAMES		3	/* acc_offset[regions]: frames available */
 #define SORA_SUM_WORDS		4
 
-#define SORA_REGION_POS_BITS	22	/* a workgroup's tile range spans fewer positions */
+#define SORA_REGION_POS_BITS	22	/* a workgroup's tile range spans fewer positions ... */
+#define SORA_RANGE_TILES_MAX	544	/* ... hence fewer tiles than this (7808 positions at least) */
 
 /* positions per tile of the scan kernel for this encoding and variant */
 uint32_t sora_scan_tile_pos(int encoding, int variant);

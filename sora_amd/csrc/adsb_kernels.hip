@@ -31,7 +31,7 @@
  *        position order
  *     4  one lane per candidate: 112 message bits are 112 consecutive elements
  *        of an NU array (funnel shifts), CRC-24 by eleven sliced table lookups,
- *        DF classification, a 6-byte record at the slot of its queue index
+ *        DF classification, a 5-byte record at the slot of its queue index
  * Resolve kernels: first_seen / add_known (known addresses), filter (the one
  * stateful rule as first_seen[A] < P), scan_counts + flatten (offsets, flat
  * list), finalize (re-slices accepted frames from the samples: bits, CRC,
@@ -261,7 +261,7 @@ adsb_scan_kernel(sora_scan_args a) {
     const uint64_t tile_end = a.n_tiles * (group + 1) / groups;
 
     uint32_t *key_out = a.key + (uint64_t) group * a.rec_cap;
-    uint16_t *tail_out = a.tail + (uint64_t) group * a.rec_cap;
+    uint8_t *tail_out = a.tail + (uint64_t) group * a.rec_cap;
     uint64_t *sq_out = a.sq + (uint64_t) group * a.sq_cap;
     uint32_t n_rec = 0;			/* workgroup-uniform */
     if (tid == 0)
@@ -301,9 +301,6 @@ adsb_scan_kernel(sora_scan_args a) {
 
     for (uint64_t tile = tile_begin; tile < tile_end; tile++) {
 	const uint64_t tile_start = tile * kTilePos;
-	/* position of the tile in the workgroup's range (< 2^SORA_REGION_POS_BITS,
-	 * sora_adsb_scan checks) */
-	const uint32_t region_off = (uint32_t) (tile - tile_begin) * (uint32_t) kTilePos;
 	/* the thread index, made opaque once per tile: LDS addresses derived from
 	 * it are then formed inside the loop as one register plus the immediate
 	 * offset field of the ds instructions; hoisted out of the loop they are a
@@ -495,11 +492,10 @@ adsb_scan_kernel(sora_scan_args a) {
 		}
 		/* key and tail (sora_scan_args); the full record only for the
 		 * squitter list */
-		const uint32_t rpos = region_off + q;
 		const uint32_t idx = n_rec + i;
 		if (idx < a.rec_cap) {
-		    key_out[idx] = payload | ((uint32_t) kind << 24) | ((rpos >> 16) << 26);
-		    tail_out[idx] = (uint16_t) rpos;
+		    key_out[idx] = payload | ((uint32_t) kind << 24) | ((q >> 8) << 26);
+		    tail_out[idx] = (uint8_t) q;
 		}
 		if (kind == SORA_REC_KIND_SQUITTER || kind == SORA_REC_KIND_CORRECTED) {
 		    const uint32_t k = atomicAdd(&s_sq_total, 1u);
@@ -514,6 +510,8 @@ adsb_scan_kernel(sora_scan_args a) {
 	    }
 	}
 	n_rec += total;
+	if (tid == 0)
+	    a.tile_end[tile] = n_rec;	/* one thin store per tile beside the records' */
 	/* The next tile refills only the M buffer before its first barrier, and
 	 * a wave passes that barrier after its last read of the queue, the
 	 * tables and the NU arrays: no barrier here unless the queue is in M. */
@@ -606,7 +604,7 @@ next_lane(uint32_t v) {
  * 0.68 ms, every sixteenth 0.59.  So phase 4 puts a record into a ring in LDS
  * (slot modulo 2048), and once a tile has completed a run of 1024 slots the
  * whole workgroup writes that run with one 16-byte store of keys and one
- * 8-byte store of tails per thread.
+ * 4-byte store of tails per thread.
  */
 constexpr uint32_t kStageUnit = 1024;		/* records per flush: four per thread */
 constexpr uint32_t kStageRing = 2 * kStageUnit;	/* a unit being filled behind one being written */
@@ -639,7 +637,10 @@ adsb_scan_direct_kernel(sora_scan_args a) {
     __shared__ uint64_t s_sq[kSqLds];
     /* the records on their way out: slot n of the region at n mod kStageRing */
     __shared__ __attribute__((aligned(16))) uint32_t s_stage_key[kStageRing];
-    __shared__ __attribute__((aligned(16))) uint16_t s_stage_tail[kStageRing];
+    __shared__ __attribute__((aligned(16))) uint8_t s_stage_tail[kStageRing];
+    /* records of the range up to and including each of its tiles (the filter
+     * finds a record's tile with it); written out as the workgroup ends */
+    __shared__ uint32_t s_tile_end[SORA_RANGE_TILES_MAX];
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63, wave = tid >> 6;
@@ -660,7 +661,7 @@ adsb_scan_direct_kernel(sora_scan_args a) {
     auto rsrc_key = __builtin_amdgcn_make_buffer_rsrc(a.key + (uint64_t) group * a.rec_cap, 0,
 	    rec_bytes > 0xfffffffcull? 0xfffffffcu : (uint32_t) rec_bytes, 0x00020000);
     auto rsrc_tail = __builtin_amdgcn_make_buffer_rsrc(a.tail + (uint64_t) group * a.rec_cap, 0,
-	    rec_bytes / 2 > 0xfffffffeull? 0xfffffffeu : (uint32_t) (rec_bytes / 2), 0x00020000);
+	    a.rec_cap, 0x00020000);
 
     {
 	const u32x4 *src = reinterpret_cast<const u32x4 *>(g_crc_slices.w);
@@ -693,25 +694,25 @@ adsb_scan_direct_kernel(sora_scan_args a) {
     auto stage_record = [&](uint32_t idx, uint32_t key, uint32_t tail) {
 	if (idx < a.rec_cap) {
 	    s_stage_key[idx & (kStageRing - 1)] = key;
-	    s_stage_tail[idx & (kStageRing - 1)] = (uint16_t) tail;
+	    s_stage_tail[idx & (kStageRing - 1)] = (uint8_t) tail;
 	}
     };
     /* Slots [n_flushed, n_flushed + kStageUnit) out of the ring into the region:
-     * thread t takes four, a 16-byte store of keys and an 8-byte store of tails
+     * thread t takes four, a 16-byte store of keys and a 4-byte store of tails
      * (kStageUnit = 4 * kThreads; the region's capacity is a multiple of 8, so
      * the bounds check drops whole stores).  `live` false: the same two stores
      * with an offset out of range -- every pass of the tile loop issues them. */
     static_assert(kStageUnit == 4 * kThreads, "one flush = four records per thread");
     auto flush_unit = [&](uint32_t t, bool live) {
 	u32x4 k4 = {0, 0, 0, 0};
-	u32x2 t2 = {0, 0};
+	uint32_t t4 = 0;
 	const uint32_t first = n_flushed + 4 * t;
 	if (live) {
 	    k4 = *reinterpret_cast<const u32x4 *>(&s_stage_key[first & (kStageRing - 1)]);
-	    t2 = *reinterpret_cast<const u32x2 *>(&s_stage_tail[first & (kStageRing - 1)]);
+	    t4 = *reinterpret_cast<const uint32_t *>(&s_stage_tail[first & (kStageRing - 1)]);
 	}
 	__builtin_amdgcn_raw_buffer_store_b128(k4, rsrc_key, live? first * 4 : 0xffffffffu, 0, 0);
-	__builtin_amdgcn_raw_buffer_store_b64(t2, rsrc_tail, live? first * 2 : 0xffffffffu, 0, 0);
+	__builtin_amdgcn_raw_buffer_store_b32(t4, rsrc_tail, live? first : 0xffffffffu, 0, 0);
     };
 
     /*
@@ -742,9 +743,6 @@ adsb_scan_direct_kernel(sora_scan_args a) {
 
     for (uint64_t tile = tile_begin; tile < tile_end; tile++) {
 	const uint64_t tile_start = tile * kTilePos;
-	/* position of the tile in the workgroup's range (< 2^SORA_REGION_POS_BITS,
-	 * sora_adsb_scan checks) */
-	const uint32_t region_off = (uint32_t) (tile - tile_begin) * (uint32_t) kTilePos;
 	const uint32_t par = (uint32_t) (tile - tile_begin) & 1;
 	/* The thread index, made opaque once per tile (see adsb_scan_kernel): the
 	 * LDS addresses derived from it are then formed inside the loop, next to
@@ -864,9 +862,8 @@ adsb_scan_direct_kernel(sora_scan_args a) {
 			payload ^= 1u << (31 - b);
 		}
 	    }
-	    const uint32_t rpos = region_off + q;
-	    *key = payload | (kind << 24) | ((rpos >> 16) << 26);
-	    *tail = rpos;
+	    *key = payload | (kind << 24) | ((q >> 8) << 26);
+	    *tail = q;
 	    if (kind == SORA_REC_KIND_SQUITTER || kind == SORA_REC_KIND_CORRECTED) {
 		const uint32_t k = atomicAdd(&s_sq_total, 1u);
 		const uint64_t r = sora_rec_make(kind, tile_start + q, payload);
@@ -932,6 +929,8 @@ adsb_scan_direct_kernel(sora_scan_args a) {
 	    lds_barrier();		/* the queue is read; the next window fills it */
 	}
 	n_rec += total;
+	if (t == 0 && tile - tile_begin < (uint64_t) SORA_RANGE_TILES_MAX)
+	    s_tile_end[tile - tile_begin] = n_rec;
 	STAMP(7);			/* candidates */
 	/* the next tile writes the other parity's NU arrays and prefix; its queue
 	 * writes come behind its barrier A */
@@ -941,12 +940,15 @@ adsb_scan_direct_kernel(sora_scan_args a) {
     {
 	/* what is left in the ring: fewer than kStageUnit + kStagePass records */
 	uint32_t *key_out = a.key + (uint64_t) group * a.rec_cap;
-	uint16_t *tail_out = a.tail + (uint64_t) group * a.rec_cap;
+	uint8_t *tail_out = a.tail + (uint64_t) group * a.rec_cap;
 	const uint32_t end = n_rec < a.rec_cap? n_rec : a.rec_cap;
 	for (uint32_t i = n_flushed + tid; i < end; i += kThreads) {
 	    key_out[i] = s_stage_key[i & (kStageRing - 1)];
 	    tail_out[i] = s_stage_tail[i & (kStageRing - 1)];
 	}
+	const uint64_t mine = tile_end - tile_begin;
+	for (uint64_t i = tid; i < mine && i < (uint64_t) SORA_RANGE_TILES_MAX; i += kThreads)
+	    a.tile_end[tile_begin + i] = s_tile_end[i];
     }
     const uint32_t n_sq = s_sq_total;
     if (tid == 0) {
@@ -1267,93 +1269,142 @@ constexpr uint32_t kFilterTargetParts = 6144;
 
 template <bool kHashed>
 __global__ void __launch_bounds__(kSmall)
-filter_kernel(sora_resolve_args a) {
+filter_kernel(sora_resolve_args a, uint32_t range_tiles) {
     /* the 2^17-bit fold of the known-address bitmap: with a few hundred planes
      * known it passes a fraction of a percent of the noise replies, and only
      * those go on to the exact bitmap and the first-seen table in L2 */
     __shared__ uint32_t s_fold[SORA_KNOWN_FOLD_WORDS];
+    /* per wave: the record counts up to the end of each tile of its scan region
+     * (sora_scan_args::tile_end); a record's position counts from its tile.
+     * Dynamic, as long as the longest range of this scan (`range_tiles`): the
+     * kernel is as fast as the CU holds waves */
+    extern __shared__ uint32_t s_tile_end[];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t region = blockIdx.x * kFilterWaves + wave;
+    const bool live = region < a.regions;		/* wave-uniform */
+    const uint32_t group = live? region / a.filter_parts : 0;
+    const uint32_t part = live? region % a.filter_parts : 0;
+    /* the tiles of the scan region, as the scan kernel computes them */
+    const uint64_t tile_first = a.n_tiles * group / a.groups;
+    uint32_t n_region_tiles = (uint32_t) (a.n_tiles * (group + 1) / a.groups - tile_first);
+    if (n_region_tiles > range_tiles)
+	n_region_tiles = range_tiles;			/* not reached: the launcher computes it */
+    uint32_t *const te = s_tile_end + wave * range_tiles;
     {
 	const u32x4 *src = reinterpret_cast<const u32x4 *>(a.known_bits +
 		SORA_KNOWN_BITMAP_WORDS);
 	for (uint32_t i = threadIdx.x; i < SORA_KNOWN_FOLD_WORDS / 4; i += kSmall)
 	    *reinterpret_cast<u32x4 *>(&s_fold[4 * i]) = src[i];
+	if (live)
+	    for (uint32_t j = lane; j < n_region_tiles; j += 64)
+		te[j] = a.tile_end[tile_first + j];
     }
     __syncthreads();
-    if (region >= a.regions)		/* wave-uniform; no barrier below */
+    if (!live)				/* no barrier below */
 	return;
-    const uint32_t group = region / a.filter_parts;
-    const uint32_t part = region % a.filter_parts;
     const uint32_t *key = a.key + (uint64_t) group * a.rec_cap;
-    const uint16_t *tail = a.tail + (uint64_t) group * a.rec_cap;
-    /* first position of the scan region: its first tile (as the scan kernel
-     * computes it) times the tile width */
-    const uint64_t region_first = (a.n_tiles * group / a.groups) * a.tile_pos;
+    const uint8_t *tail = a.tail + (uint64_t) group * a.rec_cap;
     uint64_t *acc = a.acc + (uint64_t) region * a.acc_cap;
     uint32_t n = a.rec_count[group];
     uint32_t n_acc = 0;
 
     if (n > a.rec_cap)
 	n = a.rec_cap;
+    /* where a record's tile is looked for first: tiles hold about the same number */
+    const float tiles_per_record = n > 0? (float) n_region_tiles / (float) n : 0.0f;
     /* parts begin at multiples of eight records: with rec_cap a multiple of
      * eight (sora_adsb_scan) a lane's eight keys are 32 aligned bytes and its
-     * eight tails 16 */
+     * eight tails 8 */
     const uint32_t begin = (uint32_t) ((uint64_t) n * part / a.filter_parts) & ~7u;
     const uint32_t end = part + 1 == a.filter_parts? n :
 	    (uint32_t) ((uint64_t) n * (part + 1) / a.filter_parts) & ~7u;
 
-    /* a lane takes EIGHT CONSECUTIVE records: two 16-byte loads of keys and one
-     * of tails (three load instructions per 512 records where one record per
-     * lane and load took sixteen); the kept ones go out in lane order behind a
-     * wave prefix sum of the lanes' counts */
+    /* a lane takes EIGHT CONSECUTIVE records: two 16-byte loads of keys and an
+     * 8-byte load of tails (three load instructions per 512 records where one
+     * record per lane and load took sixteen); the kept ones go out in lane order
+     * behind a wave prefix sum of the lanes' counts */
     for (uint32_t base = begin; base < end; base += 64 * kFilterUnroll) {
 	const uint32_t i0 = base + lane * kFilterUnroll;
 	uint32_t k[kFilterUnroll], t[kFilterUnroll];
 	uint64_t r[kFilterUnroll];
-	uint32_t keep = 0;
+	uint32_t keep = 0, maybe = 0, tl, tile_stop;
 	{
-	    u32x4 ka = {0, 0, 0, 0}, kb = {0, 0, 0, 0}, tt = {0, 0, 0, 0};
+	    u32x4 ka = {0, 0, 0, 0}, kb = {0, 0, 0, 0};
+	    u32x2 tt = {0, 0};
 	    if (i0 < end) {		/* the loads may pass `end`, never the region */
 		ka = *reinterpret_cast<const u32x4 *>(key + i0);
 		kb = *reinterpret_cast<const u32x4 *>(key + i0 + 4);
-		tt = *reinterpret_cast<const u32x4 *>(tail + i0);
+		tt = *reinterpret_cast<const u32x2 *>(tail + i0);
+	    }
+	    /* while those are on their way: the tile of the lane's first record,
+	     * from a guess (LDS only; nearly every batch keeps something) */
+	    tl = (uint32_t) ((float) i0 * tiles_per_record);
+	    if (tl >= n_region_tiles)
+		tl = n_region_tiles - 1;
+	    {
+		uint32_t before = tl > 0? te[tl - 1] : 0;
+		tile_stop = te[tl];
+		while (before > i0) {			/* the guess was too far */
+		    tile_stop = before;
+		    tl--;
+		    before = tl > 0? te[tl - 1] : 0;
+		}
+		while (i0 >= tile_stop && tl + 1 < n_region_tiles)
+		    tile_stop = te[++tl];
 	    }
 #pragma unroll
 	    for (int u = 0; u < 4; u++) {
 		k[u] = ka[u];
 		k[4 + u] = kb[u];
-		t[2 * u] = tt[u] & 0xffffu;
-		t[2 * u + 1] = tt[u] >> 16;
+		t[u] = (tt[0] >> (8 * u)) & 0xffu;
+		t[4 + u] = (tt[1] >> (8 * u)) & 0xffu;
 	    }
 	}
+	/* first what needs no position: nearly every record is a reply from an
+	 * address nobody has */
 #pragma unroll
 	for (int u = 0; u < kFilterUnroll; u++) {
 	    const uint32_t kind = (k[u] >> 24) & 3u;
 	    const uint32_t addr = k[u] & 0xffffffu;
-	    const uint64_t pos = region_first + (((k[u] >> 26) << 16) | t[u]);
-	    bool kept = false;
-	    r[u] = sora_rec_make(kind, pos, addr);
+	    bool open = false;
 	    if (i0 + u >= end) {
 		/* past the part: dropped */
 	    } else if (kind == SORA_REC_KIND_SQUITTER || kind == SORA_REC_KIND_CORRECTED) {
-		kept = true;
-		r[u] |= SORA_REC_ACCEPTED << 60;
+		open = true;
 	    } else if (kind == SORA_REC_KIND_REPLY) {
 		const uint32_t f = addr & ((1u << SORA_KNOWN_FOLD_BITS) - 1);
 		bool known = (s_fold[f >> 5] >> (addr & 31)) & 1;
 		if (known)
 		    known = (a.known_bits[addr >> 5] >> (addr & 31)) & 1;
-		if (known)
-		    known = (kHashed? seen_lookup_hashed(a, addr) : a.first_seen[addr]) <
-			    (a.seen_tag | (a.base_position + pos));
-		if (known)
-		    r[u] |= SORA_REC_ACCEPTED << 60;
-		kept = known || a.emit_all;
+		open = known || a.emit_all;
 	    } else {				/* SORA_REC_KIND_DIRTY */
-		kept = a.emit_all != 0;
+		open = a.emit_all != 0;
 	    }
-	    keep |= (uint32_t) kept << u;
+	    maybe |= (uint32_t) open << u;
+	}
+	/* then the position of those -- on from the tile of the lane's first
+	 * record -- and the rule that needs it */
+	if (maybe != 0) {
+#pragma unroll
+	    for (int u = 0; u < kFilterUnroll; u++) {
+		while (i0 + u >= tile_stop && tl + 1 < n_region_tiles)
+		    tile_stop = te[++tl];
+		if (maybe & (1u << u)) {
+		    const uint32_t kind = (k[u] >> 24) & 3u;
+		    const uint32_t addr = k[u] & 0xffffffu;
+		    const uint64_t pos = (tile_first + tl) * a.tile_pos + (((k[u] >> 26) << 8) | t[u]);
+		    bool accepted = kind != SORA_REC_KIND_REPLY && kind != SORA_REC_KIND_DIRTY;
+		    if (kind == SORA_REC_KIND_REPLY)	/* its address is known: since when? */
+			accepted = ((a.known_bits[addr >> 5] >> (addr & 31)) & 1) &&
+				(kHashed? seen_lookup_hashed(a, addr) : a.first_seen[addr]) <
+				(a.seen_tag | (a.base_position + pos));
+		    r[u] = sora_rec_make(kind, pos, addr);
+		    if (accepted)
+			r[u] |= SORA_REC_ACCEPTED << 60;
+		    if (accepted || a.emit_all)
+			keep |= 1u << u;
+		}
+	    }
 	}
 	if (__ballot(keep != 0) != 0) {		/* most batches of noise keep nothing */
 	    const uint32_t cnt = __popc(keep);
@@ -1902,10 +1953,16 @@ hipError_t
 sora_launch_filter(const sora_resolve_args *a, hipStream_t stream) {
     (void) hipGetLastError();
     const dim3 grid((a->regions + kFilterWaves - 1) / kFilterWaves);
+    /* tiles of the longest scan region: n_tiles * (g + 1) / groups - n_tiles * g / groups */
+    const uint64_t range = a->n_tiles / (a->groups > 0? a->groups : 1) + 1;
+    if (range > SORA_RANGE_TILES_MAX)
+	return hipErrorInvalidValue;		/* sora_adsb_scan refuses such ranges */
+    const uint32_t range_tiles = (uint32_t) range;
+    const size_t lds = (size_t) kFilterWaves * range_tiles * sizeof(uint32_t);
     if (a->seen_keys != nullptr)
-	hipLaunchKernelGGL(filter_kernel<true>, grid, dim3(kSmall), 0, stream, *a);
+	hipLaunchKernelGGL(filter_kernel<true>, grid, dim3(kSmall), lds, stream, *a, range_tiles);
     else
-	hipLaunchKernelGGL(filter_kernel<false>, grid, dim3(kSmall), 0, stream, *a);
+	hipLaunchKernelGGL(filter_kernel<false>, grid, dim3(kSmall), lds, stream, *a, range_tiles);
     return hipGetLastError();
 }
 

@@ -49,7 +49,9 @@ constexpr uint64_t kOffSqCount = kOffRecCount + aligned(kMaxGroups * 4);
 constexpr uint64_t kOffAccCount = kOffSqCount + aligned(kMaxGroups * 4);
 constexpr uint64_t kOffAccOffset = kOffAccCount + aligned(kMaxRegions * 4);
 constexpr uint64_t kOffStats = kOffAccOffset + aligned((kMaxRegions + 1) * 8);
-constexpr uint64_t kScratchUsed = kOffStats + aligned((uint64_t) kMaxGroups * SORA_STAT_WORDS * 8);
+constexpr uint64_t kOffTileEnd = kOffStats + aligned((uint64_t) kMaxGroups * SORA_STAT_WORDS * 8);
+constexpr uint64_t kTileSlots = kMaxSamples / 7808 + 16;	/* no scan kernel's tile is shorter */
+constexpr uint64_t kScratchUsed = kOffTileEnd + aligned(kTileSlots * 4);
 static_assert(kScratchUsed <= SORA_NOALLOC_SCRATCH_BYTES, "the lists do not fit the array");
 static_assert((kRecSlots & 7) == 0, "record regions are whole 8-record groups");
 
@@ -163,7 +165,8 @@ sora_adsb_decode_noalloc(int device, void *stream_, const void *d_iq, size_t nby
     a.emit_all = emit_mode == SORA_EMIT_CANDIDATES;
     a.correct = (options & SORA_OPT_CORRECT_SINGLE_BIT) != 0;
     a.key = reinterpret_cast<uint32_t *>(base + kOffRec);
-    a.tail = reinterpret_cast<uint16_t *>(a.key + kRecSlots);
+    a.tail = reinterpret_cast<uint8_t *>(a.key + kRecSlots);
+    a.tile_end = reinterpret_cast<uint32_t *>(base + kOffTileEnd);
     a.sq = reinterpret_cast<uint64_t *>(base + kOffSq);
     a.rec_cap = region_slots(groups);
     a.sq_cap = (uint32_t) (kSqSlots / groups);
@@ -183,6 +186,7 @@ sora_adsb_decode_noalloc(int device, void *stream_, const void *d_iq, size_t nby
     r.groups = groups;
     r.key = a.key;
     r.tail = a.tail;
+    r.tile_end = a.tile_end;
     r.n_tiles = n_tiles;
     r.tile_pos = tile_pos;
     r.rec_count = a.rec_count;

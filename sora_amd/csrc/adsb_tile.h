@@ -76,7 +76,7 @@
 
 /* full record (squitter lists, accepted lists): kind[63:60] | chunk-local
  * position[59:24] | address or syndrome[23:0].  The scan's candidate records
- * are the 6-byte key + tail form of sora_scan_args (adsb_kernels.h). */
+ * are the 5-byte key + tail form of sora_scan_args (adsb_kernels.h). */
 #define SORA_REC_KIND_REPLY	0ull	/* DF other than 11/17/18 */
 #define SORA_REC_KIND_SQUITTER	1ull	/* DF 11/17/18, syndrome 0 */
 #define SORA_REC_KIND_DIRTY	2ull	/* DF 11/17/18, syndrome != 0 */
