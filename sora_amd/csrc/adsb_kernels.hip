@@ -1261,7 +1261,7 @@ export_first_kernel(sora_resolve_args a, uint64_t *dst, uint64_t dst_cap,
  * and iteration.
  */
 constexpr int kFilterWaves = kSmall / 64;
-constexpr int kFilterUnroll = 8;
+constexpr int kFilterUnroll = 8;	/* 16 measured: resolve 0.52 -> 0.60 ms */
 /* a wave's loop is one round trip to HBM per iteration, so the kernel is as fast
  * as there are waves to overlap them: regions are split until there are this
  * many parts (24 waves per CU of a 256-CU part) */
@@ -1329,12 +1329,24 @@ filter_kernel(sora_resolve_args a, uint32_t range_tiles) {
 	uint64_t r[kFilterUnroll];
 	uint32_t keep = 0, maybe = 0, tl, tile_stop;
 	{
-	    u32x4 ka = {0, 0, 0, 0}, kb = {0, 0, 0, 0};
-	    u32x2 tt = {0, 0};
-	    if (i0 < end) {		/* the loads may pass `end`, never the region */
-		ka = *reinterpret_cast<const u32x4 *>(key + i0);
-		kb = *reinterpret_cast<const u32x4 *>(key + i0 + 4);
-		tt = *reinterpret_cast<const u32x2 *>(tail + i0);
+	    u32x4 kq[kFilterUnroll / 4];
+	    uint32_t tq[kFilterUnroll / 4];
+#pragma unroll
+	    for (int q = 0; q < kFilterUnroll / 4; q++) {
+		kq[q] = u32x4{0, 0, 0, 0};
+		tq[q] = 0;
+	    }
+	    if (i0 < end) {		/* the loads may pass `end`, never the list */
+#pragma unroll
+		for (int q = 0; q < kFilterUnroll / 4; q++)
+		    kq[q] = *reinterpret_cast<const u32x4 *>(key + i0 + 4 * q);
+		if constexpr (kFilterUnroll == 16) {
+		    const u32x4 tt = *reinterpret_cast<const u32x4 *>(tail + i0);
+		    tq[0] = tt[0]; tq[1] = tt[1]; tq[2] = tt[2]; tq[3] = tt[3];
+		} else {
+		    const u32x2 tt = *reinterpret_cast<const u32x2 *>(tail + i0);
+		    tq[0] = tt[0]; tq[1] = tt[1];
+		}
 	    }
 	    /* while those are on their way: the tile of the lane's first record,
 	     * from a guess (LDS only; nearly every batch keeps something) */
@@ -1353,11 +1365,9 @@ filter_kernel(sora_resolve_args a, uint32_t range_tiles) {
 		    tile_stop = te[++tl];
 	    }
 #pragma unroll
-	    for (int u = 0; u < 4; u++) {
-		k[u] = ka[u];
-		k[4 + u] = kb[u];
-		t[u] = (tt[0] >> (8 * u)) & 0xffu;
-		t[4 + u] = (tt[1] >> (8 * u)) & 0xffu;
+	    for (int u = 0; u < kFilterUnroll; u++) {
+		k[u] = kq[u / 4][u % 4];
+		t[u] = (tq[u / 4] >> (8 * (u % 4))) & 0xffu;
 	    }
 	}
 	/* first what needs no position: nearly every record is a reply from an
