@@ -16,7 +16,8 @@
  *       The next tile's samples are in flight while a tile is worked on; every
  *       pass of the tile loop issues the same vector memory operations (four
  *       loads, two stores) so that the wait for the samples is a fixed
- *       `all but the N youngest' that leaves the record stores out.
+ *       `all but the N youngest' that leaves the record stores out.  The
+ *       records collect in an LDS ring and leave 1024 at a time.
  *   adsb_scan_kernel<true>         sc16: 32-bit magnitudes staged through LDS.
  *   adsb_scan_kernel<false>        uc8 / sc8 with the magnitudes staged through
  *       LDS (SORA_ADSB_SCAN_VARIANT=0): the independent second implementation
