@@ -568,8 +568,9 @@ adsb_scan_kernel(sora_scan_args a) {
  * computed again, completely, by lane 0 of the next wave -- so phases 1-3
  * need nothing from another wave and no barrier.  What is shared through LDS
  * is the NU bit arrays (phase 4 reads 240 positions ahead), double-buffered
- * by tile parity, the hit prefix and the queue: two barriers per tile instead
- * of four, 22 KB of LDS instead of 53.
+ * by tile parity, the hit prefix, the queue and the ring the records leave
+ * through (below): two barriers per tile instead of four, 31 KB of LDS instead
+ * of 53.
  */
 template <int kThreads> struct direct_geom {
     static constexpr int waves = kThreads / 64;
@@ -586,10 +587,10 @@ next_lane(uint32_t v) {
 }
 
 /*
- * Waves per SIMD (= workgroups per CU) of the direct kernel.  Registers would
- * allow five (92 VGPRs with the next tile's samples held while a tile is worked
- * on); the LDS ring that collects the candidate records (below) allows four.
- * Three to seven all run the 1-hour capture within 2 % of each other.
+ * Waves per SIMD (= workgroups per CU) of the direct kernel: 89 VGPRs (with the
+ * next tile's samples held while a tile is worked on) and 31 KB of LDS both
+ * allow five.  Three to seven ran the 1-hour capture within 2 % of each other
+ * before the record ring; with a ring twice as long there would be four.
  */
 #ifndef SORA_DIRECT_WAVES
 #define SORA_DIRECT_WAVES 5
