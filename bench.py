@@ -67,6 +67,14 @@ def parse_args():
                     help="frame list as 28-byte wire frames (SORA_OPT_WIRE_FRAMES: the same "
                          "information, unpacked on the host on demand) or as 48-byte "
                          "struct sora_adsb_frame")
+    ap.add_argument("--schedule", choices=("two-stream", "events"), default="two-stream",
+                    help="two-stream: every capture's scan on ONE stream, back to back, and "
+                         "everything behind a scan (exchange, resolve, frame copy) on a second "
+                         "one (sora_adsb_set_resolve_stream); events: a stream per capture in "
+                         "flight, ordered S(i) R(i) S(i+1) by events (rounds 1 and 2)")
+    ap.add_argument("--resolve-priority", type=int, default=-1,
+                    help="two-stream: priority of the second stream (torch's scale: -1 high, "
+                         "0 as the scan's)")
     ap.add_argument("--overlap", action="store_true",
                     help="experiment: do not order the kernels of different captures "
                          "by events (a scan may share the GPU with a resolve)")
@@ -224,18 +232,31 @@ def main():
     # scan already runs (two captures in flight is double buffering, the way an
     # archive of recordings is worked through).  Every step still does all of
     # its work inside the timed region.
-    streams, ctxs, decs = [], [], []
+    streams, rstreams, ctxs, decs = [], [], [], []
+    two_stream = args.schedule == "two-stream" and args.inflight == 2
+    if two_stream:
+        # the scans of all captures on one stream, in the order they are begun;
+        # what follows a scan on the other (by default at high priority: its short
+        # kernels take the CU slots the scan's workgroups free as they end)
+        scan_stream = torch.cuda.Stream(device=dev, priority=0)
     for _ in range(max(1, args.inflight)):
-        st = torch.cuda.Stream(device=dev)
+        st = scan_stream if two_stream else torch.cuda.Stream(device=dev)
+        # (a resolve stream per capture in flight: the host waits on it for the
+        # frames of capture i-1 while capture i's resolve is already queued)
+        resolve_stream = (torch.cuda.Stream(device=dev, priority=args.resolve_priority)
+                          if two_stream else None)
+        rstreams.append(resolve_stream)
         ctx = AdsbContext(n_local, device=local, max_squitters=max_frames,
                           max_frames=max_frames, stream=st.cuda_stream,
-                          wire_frames=args.frames == "wire")
+                          wire_frames=args.frames == "wire",
+                          resolve_stream=resolve_stream.cuda_stream if two_stream else None)
         streams.append(st)                           # ~3x the injected frame rate
         ctxs.append(ctx)
         if collective:
             # scan -> squitter-record all-gather (RCCL) -> resolve -> every rank
             # copies its frames to its offset in a host segment shared by the node
-            decs.append(ShardedDecoder(ctx, rank, world, dev, max_frames, stream=st,
+            decs.append(ShardedDecoder(ctx, rank, world, dev, max_frames,
+                                       stream=resolve_stream if two_stream else st,
                                        gather=args.gather))
         else:
             decs.append(LocalDecoder(ctx, max_frames))
@@ -295,7 +316,7 @@ def main():
             d = decs[i % n_dec]
             if n_dec == 1 and prev is not None:
                 n, prev = finish(prev), None
-            if resolved is not None and not args.overlap:
+            if resolved is not None and not args.overlap and not two_stream:
                 streams[i % n_dec].wait_event(resolved)    # S(i) behind R(i-1)
             timed("begin", d.begin, *job)  # reset (a new capture) + scan, asynchronous
             # (N>1: squitter exchange) + resolve, queued right behind the scan: the
@@ -304,7 +325,7 @@ def main():
             # host queued this after that wait: 0.17 ms of idle GPU per step and
             # launch gaps between the small kernels, seen in the kernel trace)
             timed("exchange", d.exchange)
-            if n_dec > 1:
+            if n_dec > 1 and not two_stream:
                 resolved = mark(i)
             if prev is not None:
                 n = finish(prev)
@@ -393,6 +414,9 @@ def main():
             "injected_frames": int(len(frames)), "frames_out": int(n_frames),
             "candidates_rank0": int(counts["candidates"]),
             "captures_in_flight": len(decs),
+            "schedule": ("two streams: scans back to back on one, exchange + resolve + frame "
+                         f"copy on the other (priority {args.resolve_priority})" if two_stream
+                         else "a stream per capture in flight, S(i) R(i) S(i+1) ordered by events"),
             "frame_bytes": int(ctx.frame_dtype.itemsize),
             "host_ms_per_step": {k: round(v / args.steps * 1e3, 3) for k, v in phase_s.items()},
         },

@@ -191,10 +191,10 @@ int sora_adsb_reset(sora_adsb_ctx *ctx);
  * the buffer whole (two bytes past nbytes, inside the 16-byte alignment slack
  * every device allocation has); those bytes only reach positions the
  * p + 240 <= n_samples rule drops.  SORA_ERR_INVALID also when a workgroup's range of
- * tiles would span 2^22 positions or more (a candidate record carries its
- * position relative to that range in 22 bits): chunks beyond about 10^11
- * samples, or less with SORA_ADSB_SCAN_ROUNDS / SORA_ADSB_SCAN_MIN_TILES set
- * to few, long ranges.
+ * tiles would span 2^22 positions or more: the scan kernel and the filter keep
+ * one word per tile of a range in LDS (where the range's records of each tile
+ * end), 544 of them.  That is chunks beyond about 10^11 samples, or less with
+ * SORA_ADSB_SCAN_ROUNDS / SORA_ADSB_SCAN_MIN_TILES set to few, long ranges.
  */
 int sora_adsb_scan(sora_adsb_ctx *ctx, const void *d_iq, size_t nbytes,
 	int encoding, uint64_t base_position, uint64_t n_owned);
@@ -299,6 +299,19 @@ int sora_adsb_get_counts(sora_adsb_ctx *ctx, struct sora_adsb_counts *out); /* s
 /* How often this context has re-run a chunk with larger lists so far. */
 int sora_adsb_list_regrows(const sora_adsb_ctx *ctx);
 int sora_adsb_synchronize(sora_adsb_ctx *ctx);
+
+/*
+ * Two contexts that take turns on one GPU (two captures in flight): give both
+ * the same stream in sora_adsb_config and each a second stream here.  The
+ * scans then follow one another on the first stream with no wait between
+ * them, while everything behind a scan -- squitter export, add_known*, the
+ * resolve, the copies of sora_adsb_collect* -- runs on `stream` (a hipStream_t;
+ * NULL: back on the context's own), ordered against this context's scans by
+ * events.  The calls of one context take effect in the order they were made
+ * either way.  Waits for the context's pending work.  (No counterpart in the
+ * reference: its loop is one thread, plane-iq.c:141-194.)
+ */
+int sora_adsb_set_resolve_stream(sora_adsb_ctx *ctx, void *stream);
 
 /* Duration of the last scan kernel alone, HIP events on the context's
  * stream, in milliseconds (syncs). */

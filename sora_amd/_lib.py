@@ -10,7 +10,9 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsora_adsb_gpu.so")
+# SORA_ADSB_LIB: another build of the same library (the test suite runs its
+# list-regrow cases on the -DSORA_POISON_LISTS build this way)
+LIB_PATH = os.environ.get("SORA_ADSB_LIB") or os.path.join(_HERE, "lib", "libsora_adsb_gpu.so")
 
 OK = 0
 ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_OVERFLOW = -1, -2, -3, -4
@@ -164,6 +166,7 @@ _SIGNATURES = {
     "sora_adsb_get_counts": (C.c_int, [C.c_void_p, C.POINTER(Counts)]),
     "sora_adsb_list_regrows": (C.c_int, [C.c_void_p]),
     "sora_adsb_synchronize": (C.c_int, [C.c_void_p]),
+    "sora_adsb_set_resolve_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "sora_adsb_last_scan_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "sora_adsb_scan_kernel_name": (C.c_char_p, [C.c_void_p, C.c_int]),
     "sora_adsb_decode_noalloc": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t,

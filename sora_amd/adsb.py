@@ -73,7 +73,8 @@ class AdsbContext:
 
     def __init__(self, max_chunk_samples, device=0, emit_mode=EMIT_ACCEPTED,
                  max_candidates=0, max_squitters=0, max_frames=0, stream=None,
-                 correct_single_bit=False, fixed_lists=False, wire_frames=False):
+                 correct_single_bit=False, fixed_lists=False, wire_frames=False,
+                 resolve_stream=None):
         self.device = device
         options = _lib.OPT_CORRECT_SINGLE_BIT if correct_single_bit else 0
         if fixed_lists:
@@ -95,6 +96,13 @@ class AdsbContext:
                 lib().sora_adsb_destroy(self._h)
                 self._h = None
             raise _lib.SoraError(rc, detail)
+        if resolve_stream is not None:
+            self.set_resolve_stream(resolve_stream)
+
+    def set_resolve_stream(self, stream):
+        """Exchange, resolve and the copies of collect on `stream` (a raw
+        hipStream_t; None: back on the context's own)."""
+        check(lib().sora_adsb_set_resolve_stream(self._h, stream), self._h)
 
     def close(self):
         if getattr(self, "_h", None):

@@ -20,6 +20,17 @@ struct sora_adsb_ctx {
     int device;
     hipStream_t stream;
     bool own_stream;
+    /* Where everything behind the scan runs -- exchange, resolve, the copies to
+     * the host: the same stream unless sora_adsb_set_resolve_stream() named
+     * another.  The operations of ONE context stay in the order they were
+     * called in (an event each way, recorded only when the other stream has had
+     * work since); what the second stream buys is that another context's scan,
+     * queued on the scan stream, need not wait for this context's resolve. */
+    hipStream_t rstream;
+    hipEvent_t ev_to_resolve, ev_to_scan;
+    bool resolve_behind;	/* the scan stream has had work the resolve stream has not waited for */
+    bool scan_behind;		/* ... and the other way round */
+    bool summary_clean;		/* the summary words are zero (a reset has just cleared them) */
     hipEvent_t ev_scan_begin, ev_scan_end;
     bool scan_timed;
 
@@ -115,6 +126,40 @@ fail(sora_adsb_ctx *ctx, int code, const char *fmt, ...) {
 
 void stream_release(sora_adsb_ctx *ctx);
 
+/* Before work is queued on the scan stream / on the resolve stream: whatever the
+ * context queued on the other one comes first. */
+hipError_t
+use_scan_stream(sora_adsb_ctx *ctx) {
+    if (ctx->rstream == ctx->stream)
+	return hipSuccess;
+    if (ctx->scan_behind) {
+	hipError_t e = hipEventRecord(ctx->ev_to_scan, ctx->rstream);
+	if (e == hipSuccess)
+	    e = hipStreamWaitEvent(ctx->stream, ctx->ev_to_scan, 0);
+	if (e != hipSuccess)
+	    return e;
+	ctx->scan_behind = false;
+    }
+    ctx->resolve_behind = true;
+    return hipSuccess;
+}
+
+hipError_t
+use_resolve_stream(sora_adsb_ctx *ctx) {
+    if (ctx->rstream == ctx->stream)
+	return hipSuccess;
+    if (ctx->resolve_behind) {
+	hipError_t e = hipEventRecord(ctx->ev_to_resolve, ctx->stream);
+	if (e == hipSuccess)
+	    e = hipStreamWaitEvent(ctx->rstream, ctx->ev_to_resolve, 0);
+	if (e != hipSuccess)
+	    return e;
+	ctx->resolve_behind = false;
+    }
+    ctx->scan_behind = true;
+    return hipSuccess;
+}
+
 #define HIP_TRY(ctx, call) do { \
 	hipError_t e_ = (call); \
 	if (e_ != hipSuccess) \
@@ -158,17 +203,26 @@ dev_alloc(T **p, uint64_t n) {
  * slot for the 5 used: room for the alignment of the tails and for the
  * filter's 16-byte loads past a short region), clean squitters, accepted
  * records (per region and flat) and frames.  Allocated by sora_adsb_create()
- * from the configuration and again, larger, when a scan overflowed them.
+ * from the configuration and again, larger, when a scan overflowed them.  The
+ * scan's lists (records, squitters) and the resolve's (accepted, flat, frames)
+ * are two sets: when only the resolve's were too small the scan's keep their
+ * contents and only the resolve runs again.
  */
+void
+free_resolve_lists(sora_adsb_ctx *ctx) {
+    (void) hipFree(ctx->d_acc);
+    (void) hipFree(ctx->d_acc_flat);
+    (void) hipFree(ctx->d_frames);
+    ctx->d_acc = ctx->d_acc_flat = nullptr;
+    ctx->d_frames = nullptr;
+}
+
 void
 free_lists(sora_adsb_ctx *ctx) {
     (void) hipFree(ctx->d_rec);
     (void) hipFree(ctx->d_sq);
-    (void) hipFree(ctx->d_acc);
-    (void) hipFree(ctx->d_acc_flat);
-    (void) hipFree(ctx->d_frames);
-    ctx->d_rec = ctx->d_sq = ctx->d_acc = ctx->d_acc_flat = nullptr;
-    ctx->d_frames = nullptr;
+    ctx->d_rec = ctx->d_sq = nullptr;
+    free_resolve_lists(ctx);
 }
 
 /* shares the lists out over the workgroup regions of the scan at hand
@@ -204,16 +258,36 @@ bind_lists(sora_adsb_ctx *ctx) {
     r.frames_cap = ctx->frames_cap;
 }
 
+/* -DSORA_POISON_LISTS (test builds): a list fresh from hipMalloc holds a
+ * pattern no kernel writes, so that a kernel that reads what nothing wrote
+ * shows in the frames instead of passing on what the allocator left there */
+template <typename T> hipError_t
+list_alloc(T **p, uint64_t n) {
+    hipError_t e = dev_alloc(p, n);
+#ifdef SORA_POISON_LISTS
+    if (e == hipSuccess)
+	e = hipMemset(*p, 0xa5, (n > 0? n : 1) * sizeof(T));
+#endif
+    return e;
+}
+
+hipError_t
+alloc_resolve_lists(sora_adsb_ctx *ctx) {
+    hipError_t e;
+    if ((e = list_alloc(&ctx->d_acc, ctx->acc_total)) != hipSuccess ||
+	    (e = list_alloc(&ctx->d_acc_flat, ctx->frames_cap)) != hipSuccess ||
+	    (e = list_alloc(&ctx->d_frames, ctx->frames_cap)) != hipSuccess)
+	return e;
+    return hipSuccess;
+}
+
 hipError_t
 alloc_lists(sora_adsb_ctx *ctx) {
     hipError_t e;
-    if ((e = dev_alloc(&ctx->d_rec, ctx->rec_total + 8)) != hipSuccess ||
-	    (e = dev_alloc(&ctx->d_sq, ctx->sq_total)) != hipSuccess ||
-	    (e = dev_alloc(&ctx->d_acc, ctx->acc_total)) != hipSuccess ||
-	    (e = dev_alloc(&ctx->d_acc_flat, ctx->frames_cap)) != hipSuccess ||
-	    (e = dev_alloc(&ctx->d_frames, ctx->frames_cap)) != hipSuccess)
+    if ((e = list_alloc(&ctx->d_rec, ctx->rec_total + 8)) != hipSuccess ||
+	    (e = list_alloc(&ctx->d_sq, ctx->sq_total)) != hipSuccess)
 	return e;
-    return hipSuccess;
+    return alloc_resolve_lists(ctx);
 }
 
 } /* namespace */
@@ -258,6 +332,8 @@ sora_adsb_destroy(sora_adsb_ctx *ctx) {
     (void) hipSetDevice(ctx->device);
     if (ctx->stream != nullptr)
 	(void) hipStreamSynchronize(ctx->stream);
+    if (ctx->rstream != nullptr && ctx->rstream != ctx->stream)
+	(void) hipStreamSynchronize(ctx->rstream);
     if (ctx->st.active) {
 	(void) hipStreamSynchronize(ctx->st.copy);
 	stream_release(ctx);
@@ -274,7 +350,6 @@ sora_adsb_destroy(sora_adsb_ctx *ctx) {
     (void) hipFree(ctx->d_acc_count);
     (void) hipFree(ctx->d_tile_end);
     (void) hipFree(ctx->d_stage);
-    (void) hipFree(ctx->d_summary);
     if (ctx->h_summary != nullptr)
 	(void) hipHostFree(ctx->h_summary);
     if (ctx->h_counts != nullptr)
@@ -285,6 +360,10 @@ sora_adsb_destroy(sora_adsb_ctx *ctx) {
 	(void) hipEventDestroy(ctx->ev_scan_begin);
     if (ctx->ev_scan_end != nullptr)
 	(void) hipEventDestroy(ctx->ev_scan_end);
+    if (ctx->ev_to_resolve != nullptr)
+	(void) hipEventDestroy(ctx->ev_to_resolve);
+    if (ctx->ev_to_scan != nullptr)
+	(void) hipEventDestroy(ctx->ev_to_scan);
     if (ctx->own_stream && ctx->stream != nullptr)
 	(void) hipStreamDestroy(ctx->stream);
     free(ctx);
@@ -306,6 +385,7 @@ sora_adsb_reset(sora_adsb_ctx *ctx) {
     if (ctx == nullptr)
 	return SORA_ERR_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, use_scan_stream(ctx));
     /* forgetting every address = the next epoch: what the table holds is then
      * larger than anything stored or asked from now on (sora_resolve_args::
      * seen_tag).  Only the first use and a wrap of the 24-bit epoch fill it. */
@@ -316,8 +396,11 @@ sora_adsb_reset(sora_adsb_ctx *ctx) {
     } else {
 	ctx->epoch++;
     }
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_known_bits, 0, SORA_KNOWN_WORDS * sizeof(uint32_t),
-	    ctx->stream));
+    /* the summary words lie behind the bitmap: one fill clears both (a new
+     * capture's reset + scan is then one memset, not two) */
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_known_bits, 0, SORA_KNOWN_WORDS * sizeof(uint32_t) +
+	    kSummaryAlloc * sizeof(uint64_t), ctx->stream));
+    ctx->summary_clean = true;
     ctx->scanned = ctx->resolved = false;
     return SORA_OK;
 }
@@ -359,8 +442,11 @@ sora_adsb_create(sora_adsb_ctx **out, int device, const sora_adsb_config *cfg) {
 	HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamDefault));
 	ctx->own_stream = true;
     }
+    ctx->rstream = ctx->stream;
     HIP_TRY(ctx, hipEventCreate(&ctx->ev_scan_begin));
     HIP_TRY(ctx, hipEventCreate(&ctx->ev_scan_end));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_to_resolve, hipEventDisableTiming));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_to_scan, hipEventDisableTiming));
 
     /* the scan kernels run sora_scan_groups_per_cu() workgroups on every CU
      * (what their LDS lets a CU hold): at most 4 */
@@ -394,7 +480,7 @@ sora_adsb_create(sora_adsb_ctx **out, int device, const sora_adsb_config *cfg) {
     /* no scan kernel's tile has fewer than 7808 positions */
     ctx->tile_slots = n / 7808 + 16;
     if (alloc_lists(ctx) != hipSuccess ||
-	    dev_alloc(&ctx->d_known_bits, SORA_KNOWN_WORDS) != hipSuccess ||
+	    dev_alloc(&ctx->d_known_bits, SORA_KNOWN_WORDS + 2 * kSummaryAlloc) != hipSuccess ||
 	    dev_alloc(&ctx->d_first_seen, SORA_ADDRESSES) != hipSuccess ||
 	    dev_alloc(&ctx->d_stats, (uint64_t) g * SORA_STAT_WORDS) != hipSuccess ||
 	    dev_alloc(&ctx->d_acc_offset, nr + 1) != hipSuccess ||
@@ -403,9 +489,10 @@ sora_adsb_create(sora_adsb_ctx **out, int device, const sora_adsb_config *cfg) {
 	    dev_alloc(&ctx->d_rec_count, g) != hipSuccess ||
 	    dev_alloc(&ctx->d_sq_count, g) != hipSuccess ||
 	    dev_alloc(&ctx->d_acc_count, nr) != hipSuccess ||
-	    dev_alloc(&ctx->d_tile_end, ctx->tile_slots) != hipSuccess ||
-	    dev_alloc(&ctx->d_summary, kSummaryAlloc) != hipSuccess)
+	    dev_alloc(&ctx->d_tile_end, ctx->tile_slots) != hipSuccess)
 	return fail(ctx, SORA_ERR_NOMEM, "hipMalloc of the device lists failed");
+    /* SORA_KNOWN_WORDS * 4 bytes is a multiple of 256: the words are aligned */
+    ctx->d_summary = reinterpret_cast<uint64_t *>(ctx->d_known_bits + SORA_KNOWN_WORDS);
     HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_summary),
 	    SORA_SUM_WORDS * sizeof(uint64_t), hipHostMallocDefault));
     HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_counts),
@@ -461,8 +548,8 @@ sora_adsb_scan(sora_adsb_ctx *ctx, const void *d_iq, size_t nbytes, int encoding
     if (ctx->rec_total / groups < 8)
 	groups = ctx->rec_total / 8 > 0? (uint32_t) (ctx->rec_total / 8) : 1;
 
-    /* a record carries its position relative to the first tile of its
-     * workgroup's range in SORA_REGION_POS_BITS bits */
+    /* the tiles of a workgroup's range have a word each in the LDS of the scan
+     * kernel and of the filter: SORA_RANGE_TILES_MAX (adsb_kernels.h) */
     if ((n_tiles / groups + 1) * sora_scan_tile_pos(encoding, (int) ctx->scan_variant) >=
 	    (1ull << SORA_REGION_POS_BITS))
 	return fail(ctx, SORA_ERR_INVALID, "chunk of %llu samples is too long for %u scan regions",
@@ -524,8 +611,11 @@ sora_adsb_scan(sora_adsb_ctx *ctx, const void *d_iq, size_t nbytes, int encoding
     ctx->last.base_position = base_position;
     ctx->last.n_owned = n_owned;
 
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_summary, 0, kSummaryAlloc * sizeof(uint64_t),
-	    ctx->stream));
+    HIP_TRY(ctx, use_scan_stream(ctx));
+    if (!ctx->summary_clean)
+	HIP_TRY(ctx, hipMemsetAsync(ctx->d_summary, 0, kSummaryAlloc * sizeof(uint64_t),
+		ctx->stream));
+    ctx->summary_clean = false;
     HIP_TRY(ctx, hipEventRecord(ctx->ev_scan_begin, ctx->stream));
     HIP_TRY(ctx, sora_launch_scan(&a, groups, (int) ctx->scan_variant, ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_scan_end, ctx->stream));
@@ -542,15 +632,16 @@ export_first(sora_adsb_ctx *ctx) {
     if (ctx->exported)
 	return SORA_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, use_resolve_stream(ctx));
     if (!ctx->merged) {
-	HIP_TRY(ctx, sora_launch_first_seen(&ctx->res, ctx->stream));
+	HIP_TRY(ctx, sora_launch_first_seen(&ctx->res, ctx->rstream));
 	ctx->merged = true;
     }
     HIP_TRY(ctx, sora_launch_export_first(&ctx->res, ctx->d_export, ctx->export_cap,
-	    ctx->d_sq_offset, ctx->stream));
+	    ctx->d_sq_offset, ctx->rstream));
     HIP_TRY(ctx, hipMemcpyAsync(&ctx->h_total[0], ctx->d_sq_offset, sizeof(uint64_t),
-	    hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	    hipMemcpyDeviceToHost, ctx->rstream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->rstream));
     if (ctx->h_total[0] > ctx->export_cap)
 	return fail(ctx, SORA_ERR_OVERFLOW, "%llu addresses first seen in one scan "
 		"exceed the export list (%llu)", (unsigned long long) ctx->h_total[0],
@@ -587,7 +678,7 @@ sora_adsb_copy_squitters(sora_adsb_ctx *ctx, void *d_dst, size_t cap_records) {
     ctx->exchanged = true;
     if (n > 0)
 	HIP_TRY(ctx, hipMemcpyAsync(d_dst, ctx->d_export, n * sizeof(uint64_t),
-		hipMemcpyDeviceToDevice, ctx->stream));
+		hipMemcpyDeviceToDevice, ctx->rstream));
     return SORA_OK;
 }
 
@@ -596,8 +687,9 @@ sora_adsb_add_known(sora_adsb_ctx *ctx, const void *d_records, size_t n_records)
     if (ctx == nullptr || (d_records == nullptr && n_records != 0))
 	return SORA_ERR_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, use_resolve_stream(ctx));
     HIP_TRY(ctx, sora_launch_add_known(ctx->d_first_seen, ctx->d_known_bits, seen_tag(ctx),
-	    static_cast<const uint64_t *>(d_records), n_records, ctx->stream));
+	    static_cast<const uint64_t *>(d_records), n_records, ctx->rstream));
     return SORA_OK;
 }
 
@@ -609,13 +701,14 @@ sora_adsb_export_block(sora_adsb_ctx *ctx, void *d_block, size_t block_records) 
     if (!ctx->scanned)
 	return fail(ctx, SORA_ERR_STATE, "no scan to export squitters of");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, use_resolve_stream(ctx));
     if (!ctx->merged) {
-	HIP_TRY(ctx, sora_launch_first_seen(&ctx->res, ctx->stream));
+	HIP_TRY(ctx, sora_launch_first_seen(&ctx->res, ctx->rstream));
 	ctx->merged = true;
     }
     uint64_t *blk = static_cast<uint64_t *>(d_block);
     HIP_TRY(ctx, sora_launch_export_first(&ctx->res, blk + 1, block_records - 1, blk,
-	    ctx->stream));
+	    ctx->rstream));
     ctx->exchanged = true;
     return SORA_OK;
 }
@@ -627,10 +720,11 @@ sora_adsb_add_known_blocks(sora_adsb_ctx *ctx, const void *d_blocks, size_t n_bl
 	    block_records > 0xffffffffull || n_blocks > 65535)
 	return SORA_ERR_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, use_resolve_stream(ctx));
     HIP_TRY(ctx, sora_launch_add_known_blocks(ctx->d_first_seen, ctx->d_known_bits,
 	    seen_tag(ctx), static_cast<const uint64_t *>(d_blocks), (uint32_t) n_blocks,
 	    (uint32_t) block_records, skip_block < 0? 0xffffffffu : (uint32_t) skip_block,
-	    ctx->stream));
+	    ctx->rstream));
     return SORA_OK;
 }
 
@@ -641,14 +735,15 @@ sora_adsb_resolve(sora_adsb_ctx *ctx) {
     if (!ctx->scanned)
 	return fail(ctx, SORA_ERR_STATE, "resolve without a scan");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, use_resolve_stream(ctx));
     if (!ctx->merged) {
-	HIP_TRY(ctx, sora_launch_first_seen(&ctx->res, ctx->stream));
+	HIP_TRY(ctx, sora_launch_first_seen(&ctx->res, ctx->rstream));
 	ctx->merged = true;
     }
-    HIP_TRY(ctx, sora_launch_filter(&ctx->res, ctx->stream));
+    HIP_TRY(ctx, sora_launch_filter(&ctx->res, ctx->rstream));
     HIP_TRY(ctx, sora_launch_scan_counts(ctx->d_acc_count, ctx->res.acc_cap,
-	    ctx->d_acc_offset, ctx->res.regions, ctx->d_summary + SORA_SUM_FRAMES, ctx->stream));
-    HIP_TRY(ctx, sora_launch_finalize(&ctx->res, ctx->cus, ctx->stream));
+	    ctx->d_acc_offset, ctx->res.regions, ctx->d_summary + SORA_SUM_FRAMES, ctx->rstream));
+    HIP_TRY(ctx, sora_launch_finalize(&ctx->res, ctx->cus, ctx->rstream));
     ctx->resolved = true;
     return SORA_OK;
 }
@@ -668,9 +763,10 @@ sora_adsb_submit_host(sora_adsb_ctx *ctx, const void *h_iq, size_t nbytes,
     if (ctx == nullptr || (h_iq == nullptr && nbytes != 0))
 	return SORA_ERR_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    /* the last resolve may still read the staging buffer */
+    HIP_TRY(ctx, use_scan_stream(ctx));
     const size_t need = ((nbytes + 15) & ~(size_t) 15) + 16;
     if (ctx->stage_bytes < need) {
-	/* the stream may still read the old staging buffer */
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	(void) hipFree(ctx->d_stage);
 	ctx->d_stage = nullptr;
@@ -693,21 +789,22 @@ int
 fetch_counts(sora_adsb_ctx *ctx, bool *overflow) {
     const uint32_t g = ctx->groups;
 
+    HIP_TRY(ctx, use_resolve_stream(ctx));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_counts, ctx->d_rec_count,
-	    g * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+	    g * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->rstream));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_counts + g, ctx->d_sq_count,
-	    g * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+	    g * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->rstream));
     const uint32_t nr = ctx->res.regions;
     if (ctx->resolved) {
 	HIP_TRY(ctx, hipMemcpyAsync(ctx->h_counts + 2 * g, ctx->d_acc_count,
-		nr * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+		nr * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->rstream));
 	HIP_TRY(ctx, hipMemcpyAsync(&ctx->h_total[1], ctx->d_acc_offset + nr,
-		sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+		sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->rstream));
     }
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_stats, ctx->d_stats,
 	    (size_t) g * SORA_STAT_WORDS * sizeof(uint64_t),
-	    hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	    hipMemcpyDeviceToHost, ctx->rstream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->rstream));
 
     *overflow = false;
     for (uint32_t i = 0; i < g; i++) {
@@ -741,8 +838,6 @@ ensure_complete(sora_adsb_ctx *ctx, bool *overflow) {
 	int rc = fetch_counts(ctx, overflow);
 	if (rc != SORA_OK || !*overflow)
 	    return rc;
-	if ((ctx->cfg.options & SORA_OPT_FIXED_LISTS) != 0 || attempt >= 5)
-	    return SORA_OK;
 
 	const uint32_t g = ctx->groups, nr = ctx->res.regions;
 	uint64_t need_rec = 0, need_sq = 0, need_acc = 0, need_frames = 0;
@@ -757,9 +852,27 @@ ensure_complete(sora_adsb_ctx *ctx, bool *overflow) {
 		need_acc = ctx->h_counts[2 * g + i];
 	    need_frames += ctx->h_counts[2 * g + i];
 	}
+	/* the three ways out with *overflow still set, each with what the caller
+	 * can do about it (sora_adsb_last_error) */
+	const auto give_up = [&](const char *why) {
+	    (void) fail(ctx, SORA_ERR_OVERFLOW, "%s: the fullest of %u scan regions needs %llu "
+		    "record and %llu squitter slots (it has %u and %u), the fullest of %u "
+		    "accepted regions %llu (it has %u), %llu frames in all (room for %llu)", why,
+		    g, (unsigned long long) need_rec, (unsigned long long) need_sq,
+		    ctx->res.rec_cap, ctx->res.sq_cap, nr, (unsigned long long) need_acc,
+		    ctx->res.acc_cap, (unsigned long long) need_frames,
+		    (unsigned long long) ctx->frames_cap);
+	    return SORA_OK;
+	};
+	if ((ctx->cfg.options & SORA_OPT_FIXED_LISTS) != 0)
+	    return give_up("a device list overflowed and SORA_OPT_FIXED_LISTS keeps them as "
+		    "they are; raise max_candidates / max_squitters / max_frames");
+	if (attempt >= 5)
+	    return give_up("a device list still overflowed after five re-runs with larger lists");
 	const bool scan_over = need_rec > ctx->res.rec_cap || need_sq > ctx->res.sq_cap;
 	if (need_sq > ctx->res.sq_cap && ctx->exchanged)
-	    return SORA_OK;
+	    return give_up("the squitter list overflowed and its truncated export has already "
+		    "left this context: raise max_squitters and run every shard again");
 
 	/* a quarter more than was needed, shared out evenly like the lists are */
 	const auto grown = [](uint64_t per_region, uint32_t regions) {
@@ -782,23 +895,40 @@ ensure_complete(sora_adsb_ctx *ctx, bool *overflow) {
 	if (frames_cap < acc_total && scan_over)
 	    frames_cap = acc_total;
 
-	/* every kernel that uses the old lists is done: fetch_counts waited */
+	/* Every kernel that uses the old lists is done: fetch_counts waited.  A
+	 * larger export list first, while nothing has been freed: a failure there
+	 * leaves the context as it was. */
 	const bool was_resolved = ctx->resolved;
-	free_lists(ctx);
-	ctx->rec_total = rec_total;
-	ctx->sq_total = sq_total;
-	ctx->acc_total = acc_total;
-	ctx->frames_cap = frames_cap;
-	uint64_t export_cap = sq_total < (1ull << 22)? sq_total : (1ull << 22);
+	const uint64_t export_cap = sq_total < (1ull << 22)? sq_total : (1ull << 22);
 	if (export_cap > ctx->export_cap) {
-	    (void) hipFree(ctx->d_export);
-	    ctx->d_export = nullptr;
-	    ctx->export_cap = export_cap;
-	    if (dev_alloc(&ctx->d_export, export_cap) != hipSuccess)
+	    uint64_t *d_export = nullptr;
+	    if (dev_alloc(&d_export, export_cap) != hipSuccess)
 		return fail(ctx, SORA_ERR_NOMEM, "export list of %llu records",
 			(unsigned long long) export_cap);
+	    (void) hipFree(ctx->d_export);
+	    ctx->d_export = d_export;
+	    ctx->export_cap = export_cap;
+	    ctx->exported = false;
 	}
-	if (alloc_lists(ctx) != hipSuccess) {
+	/* The scan's lists (records, squitters) are replaced only when one of THEM
+	 * was too small, and then the scan runs again.  When only the accepted or
+	 * the frame list was, the records stay where they are -- the filter is
+	 * about to read them again -- and only the resolve's lists are replaced. */
+	hipError_t e;
+	if (scan_over) {
+	    free_lists(ctx);
+	    ctx->rec_total = rec_total;
+	    ctx->sq_total = sq_total;
+	    ctx->acc_total = acc_total;
+	    ctx->frames_cap = frames_cap;
+	    e = alloc_lists(ctx);
+	} else {
+	    free_resolve_lists(ctx);
+	    ctx->acc_total = acc_total;
+	    ctx->frames_cap = frames_cap;
+	    e = alloc_resolve_lists(ctx);
+	}
+	if (e != hipSuccess) {
 	    ctx->scanned = ctx->resolved = false;
 	    return fail(ctx, SORA_ERR_NOMEM, "lists of %llu records, %llu squitters, %llu "
 		    "frames after an overflow", (unsigned long long) rec_total,
@@ -815,7 +945,7 @@ ensure_complete(sora_adsb_ctx *ctx, bool *overflow) {
 	} else {
 	    bind_lists(ctx);
 	    HIP_TRY(ctx, hipMemsetAsync(ctx->d_summary + SORA_SUM_ACC_OVER, 0, sizeof(uint64_t),
-		    ctx->stream));
+		    ctx->rstream));
 	}
 	if (was_resolved && (rc = sora_adsb_resolve(ctx)) != SORA_OK)
 	    return rc;
@@ -837,10 +967,11 @@ collect_common(sora_adsb_ctx *ctx, void *dst, size_t cap, size_t *n,
     if (!ctx->resolved)
 	return fail(ctx, SORA_ERR_STATE, "collect without a resolve");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, use_resolve_stream(ctx));
     /* the common case in one small copy: every list held */
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_summary, ctx->d_summary,
-	    SORA_SUM_WORDS * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	    SORA_SUM_WORDS * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->rstream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->rstream));
     if (ctx->h_summary[SORA_SUM_REC_OVER] != 0 || ctx->h_summary[SORA_SUM_SQ_OVER] != 0 ||
 	    ctx->h_summary[SORA_SUM_ACC_OVER] != 0 ||
 	    ctx->h_summary[SORA_SUM_FRAMES] > ctx->frames_cap) {
@@ -849,9 +980,7 @@ collect_common(sora_adsb_ctx *ctx, void *dst, size_t cap, size_t *n,
 	if (rc != SORA_OK)
 	    return rc;
 	if (overflow)
-	    return fail(ctx, SORA_ERR_OVERFLOW,
-		    "a device list overflowed and could not be grown; raise max_candidates / "
-		    "max_squitters / max_frames (see sora_adsb_get_counts)");
+	    return SORA_ERR_OVERFLOW;	/* ensure_complete has said which list and why */
     } else {
 	ctx->h_total[1] = ctx->h_summary[SORA_SUM_FRAMES];
     }
@@ -860,8 +989,8 @@ collect_common(sora_adsb_ctx *ctx, void *dst, size_t cap, size_t *n,
     const size_t take = total < cap? (size_t) total : cap;
     if (take > 0) {
 	HIP_TRY(ctx, hipMemcpyAsync(dst, ctx->d_frames, take * (wire?
-		sizeof(sora_adsb_wire_frame) : sizeof(sora_adsb_frame)), kind, ctx->stream));
-	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+		sizeof(sora_adsb_wire_frame) : sizeof(sora_adsb_frame)), kind, ctx->rstream));
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->rstream));
     }
     return SORA_OK;
 }
@@ -1108,7 +1237,7 @@ sora_adsb_stream_next(sora_adsb_ctx *ctx, const sora_adsb_frame **frames, size_t
 	    s.n_owned[cur]);
     if (rc != SORA_OK)
 	return rc;
-    HIP_TRY(ctx, hipEventRecord(s.ev_free[cur], ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(s.ev_free[cur], ctx->rstream));
     /* the next block: read and copied while the kernels run */
     if (!s.last[cur] && (rc = stream_fill(ctx, cur ^ 1)) != SORA_OK)
 	return rc;
@@ -1146,6 +1275,8 @@ sora_adsb_stream_end(sora_adsb_ctx *ctx) {
     (void) hipSetDevice(ctx->device);
     (void) hipStreamSynchronize(ctx->st.copy);
     (void) hipStreamSynchronize(ctx->stream);
+    if (ctx->rstream != ctx->stream)
+	(void) hipStreamSynchronize(ctx->rstream);
     stream_release(ctx);
     return SORA_OK;
 }
@@ -1178,6 +1309,31 @@ sora_adsb_synchronize(sora_adsb_ctx *ctx) {
 	return SORA_ERR_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->rstream != ctx->stream)
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->rstream));
+    return SORA_OK;
+}
+
+/*
+ * Everything behind the scan -- squitter export, add_known, resolve, the copies
+ * of collect -- on a stream of its own (NULL: back on the scan's).  The calls
+ * of this context keep their order; what changes is that work ANOTHER context
+ * queues on the scan stream (the next capture's scan) no longer waits behind
+ * this context's resolve, and this context's frame copy no longer waits behind
+ * that scan.
+ */
+extern "C" int
+sora_adsb_set_resolve_stream(sora_adsb_ctx *ctx, void *stream) {
+    if (ctx == nullptr)
+	return SORA_ERR_INVALID;
+    if (ctx->st.active)
+	return fail(ctx, SORA_ERR_STATE, "a stream of blocks is open");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->rstream != ctx->stream)
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->rstream));
+    ctx->rstream = stream != nullptr? static_cast<hipStream_t>(stream) : ctx->stream;
+    ctx->resolve_behind = ctx->scan_behind = false;
     return SORA_OK;
 }
 
@@ -1211,6 +1367,7 @@ sora_adsb_magnitude(sora_adsb_ctx *ctx, const void *d_iq, size_t nbytes,
     if (bps == 0 || (d_iq == nullptr && nbytes != 0) || (d_m == nullptr && nbytes != 0))
 	return fail(ctx, SORA_ERR_INVALID, "bad magnitude arguments");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, use_scan_stream(ctx));
     HIP_TRY(ctx, sora_launch_magnitude(static_cast<const uint8_t *>(d_iq),
 	    nbytes / (size_t) bps, encoding, d_m, ctx->stream));
     return SORA_OK;

@@ -126,8 +126,12 @@ struct sora_resolve_args {
 #define SORA_SUM_FRAMES		3	/* acc_offset[regions]: frames available */
 #define SORA_SUM_WORDS		4
 
-#define SORA_REGION_POS_BITS	22	/* a workgroup's tile range spans fewer positions ... */
-#define SORA_RANGE_TILES_MAX	544	/* ... hence fewer tiles than this (7808 positions at least) */
+/* The tiles of one workgroup's range: the scan kernel and the filter keep a
+ * word per tile of a range in LDS (sora_scan_args::tile_end).  sora_adsb_scan
+ * checks it as positions: fewer than 2^SORA_REGION_POS_BITS per range, which at
+ * 7808 positions per tile or more is fewer than SORA_RANGE_TILES_MAX tiles. */
+#define SORA_REGION_POS_BITS	22
+#define SORA_RANGE_TILES_MAX	544
 
 /* positions per tile of the scan kernel for this encoding and variant */
 uint32_t sora_scan_tile_pos(int encoding, int variant);

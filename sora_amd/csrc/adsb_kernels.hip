@@ -1742,11 +1742,15 @@ finalize_kernel(sora_resolve_args a) {
 	total = a.frames_cap;
     if (a.n_samples < SORA_WINDOW)
 	total = 0;
-    /* a wave takes 64 consecutive frames at a time: one coalesced load brings
-     * their records (no dependent record fetch per frame); row g of round i
-     * works on frame 4 i + g */
-    for (uint64_t batch = gw * 64; batch < total; batch += n_waves * 64) {
-	const uint32_t cnt = total - batch < 64? (uint32_t) (total - batch) : 64u;
+    /* a wave takes up to 64 consecutive frames at a time: one coalesced load
+     * brings their records (no dependent record fetch per frame); row g of round
+     * i works on frame 4 i + g.  A short list goes out in batches of 32 or 16 so
+     * that every wave of the grid has one: the rounds of a batch are dependent
+     * trips to memory, and a 900 M-sample shard's 0.2 M frames in batches of 64
+     * keep one wave in seven busy for eight rounds each (33 -> 30 us). */
+    const uint64_t per = total >= 64 * n_waves? 64 : total >= 32 * n_waves? 32 : 16;
+    for (uint64_t batch = gw * per; batch < total; batch += n_waves * per) {
+	const uint32_t cnt = total - batch < per? (uint32_t) (total - batch) : (uint32_t) per;
 	const uint64_t mine = lane < cnt? a.acc_flat[batch + lane] : 0;
 	const bool any_corrected =
 		__ballot(lane < cnt && (sora_rec_kind(mine) & 3) == SORA_REC_KIND_CORRECTED) != 0;

@@ -69,31 +69,52 @@ namespace {
 constexpr int kMaxDevices = 64;
 
 struct device_slot {
-    std::once_flag once;
-    hipError_t status = hipErrorNotInitialized;
+    std::mutex lock;
+    bool ready = false;		/* set once the look-ups below have all succeeded */
     unsigned char *ptr = nullptr;	/* this device's copy of `scratch` */
     uint32_t cus = 0;
     bool gfx950 = false;
 } g_dev[kMaxDevices];
 
-/* once per device, with that device current */
-void
+/* Per device, with that device current: what kind it is and where its copy of
+ * the array lies.  A look-up that fails is not remembered: the next call tries
+ * again (a transient failure must not disable the device for the process). */
+hipError_t
 device_setup(int device) {
     device_slot &d = g_dev[device];
+    std::lock_guard<std::mutex> hold(d.lock);
+    if (d.ready)
+	return hipSuccess;
     hipDeviceProp_t prop;
     void *p = nullptr;
 
-    d.status = hipGetDeviceProperties(&prop, device);
-    if (d.status != hipSuccess)
-	return;
+    hipError_t e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess)
+	return e;
     d.gfx950 = strncmp(prop.gcnArchName, "gfx950", 6) == 0;
     d.cus = prop.multiProcessorCount > 0? (uint32_t) prop.multiProcessorCount : 1;
-    if (!d.gfx950)
-	return;
-    d.status = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
-    if (d.status == hipSuccess)
+    if (d.gfx950) {
+	e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+	if (e != hipSuccess)
+	    return e;
 	d.ptr = static_cast<unsigned char *>(p);
+    }
+    d.ready = true;
+    return hipSuccess;
 }
+
+/* the caller's current device, put back when the entry point returns */
+struct device_guard {
+    int before = -1;
+    device_guard() {
+	if (hipGetDevice(&before) != hipSuccess)
+	    before = -1;
+    }
+    ~device_guard() {
+	if (before >= 0)
+	    (void) hipSetDevice(before);
+    }
+};
 
 int
 bytes_per_sample(int encoding) {
@@ -125,12 +146,12 @@ sora_adsb_decode_noalloc(int device, void *stream_, const void *d_iq, size_t nby
 	return SORA_ERR_INVALID;
     if (device < 0 || device >= kMaxDevices)
 	return SORA_ERR_NO_DEVICE;
+    device_guard restore;
     if (hipSetDevice(device) != hipSuccess)
 	return SORA_ERR_NO_DEVICE;
-    device_slot &dev = g_dev[device];
-    std::call_once(dev.once, device_setup, device);
-    if (dev.status != hipSuccess)
+    if (device_setup(device) != hipSuccess)
 	return SORA_ERR_HIP;
+    device_slot &dev = g_dev[device];
     if (!dev.gfx950 || dev.ptr == nullptr)
 	return SORA_ERR_NO_DEVICE;
     unsigned char *const base = dev.ptr;

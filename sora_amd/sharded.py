@@ -46,7 +46,7 @@ def _frame_dtype(ctx):
     SORA_OPT_WIRE_FRAMES (sora_amd.unpack_frames turns them into the former)."""
     return getattr(ctx, "frame_dtype", FRAME_DTYPE)
 
-HEADER_WORDS = 8                    # u64 per rank: seq, n_frames, ack (rank 0), pad
+HEADER_WORDS = 8                    # u64 per rank: seq, n_frames, ack (rank 0), failed, pad
 EXCHANGE_RECORDS = 8192             # words of a rank's exchange block: count + records
 SPIN_TIMEOUT_S = 300.0
 
@@ -104,10 +104,11 @@ class LocalDecoder:
 class ShardedDecoder:
     """Drives one context per rank through scan -> exchange -> resolve -> gather.
 
-    `stream`: the torch.cuda.Stream the context was created on (AdsbContext(...,
-    stream=s.cuda_stream)); collectives and context launches are then ordered by
-    that one stream.  None: the context must be on torch's current stream, or be
-    a CPU stand-in."""
+    `stream`: the torch.cuda.Stream the context queues its exchange and resolve
+    on -- the one it was created on (AdsbContext(..., stream=s.cuda_stream)), or
+    its resolve stream if it has one (resolve_stream=s.cuda_stream); collectives
+    and context launches are then ordered by that one stream.  None: the context
+    must be on torch's current stream, or be a CPU stand-in."""
 
     def __init__(self, ctx, rank, world, device, max_frames, group=None, stream=None,
                  gather="shm", exchange_records=EXCHANGE_RECORDS):
@@ -138,6 +139,7 @@ class ShardedDecoder:
         self.ns = [0] * world
         self._registered = None
         self._mm = None
+        self.header = None
         if gather == "shm" and not self._open_segment():
             self.gather = gather = "collective"  # no room in /dev/shm on this node
         if gather != "shm":
@@ -212,11 +214,30 @@ class ShardedDecoder:
         return [int(x) for x in counts.tolist()]
 
     def _spin(self, ready, what):
+        """Waits for another rank's word in the header -- or for its failure
+        mark: a rank that raises anywhere between begin() and finish() says so
+        in the header first (_failing), and the ranks that wait for it raise at
+        once instead of spinning until the timeout."""
         t0 = time.monotonic()
         while not ready():
+            failed = np.flatnonzero(self.header[:, 3])
+            if failed.size:
+                raise RuntimeError(f"rank {self.rank}: rank {int(failed[0])} failed while this "
+                                   f"rank waited for {what}")
             if time.monotonic() - t0 > SPIN_TIMEOUT_S:
                 raise RuntimeError(f"rank {self.rank}: timed out waiting for {what}")
             time.sleep(0)
+
+    @contextlib.contextmanager
+    def _failing(self):
+        """Whatever is raised inside is marked in the shared header before it
+        goes on up (the mark stays: the segment is not usable afterwards)."""
+        try:
+            yield
+        except BaseException:
+            if self.gather == "shm" and self.header is not None:
+                self.header[self.rank, 3] = self.seq + 1
+            raise
 
     # -- the three phases ---------------------------------------------------
     def begin(self, d_iq, nbytes, encoding, base_position, n_owned, reset=True):
@@ -224,14 +245,15 @@ class ShardedDecoder:
             # the reader lets go of the previous result of this decoder
             self.header[0, 2] = self.seq
         self.seq += 1
-        if reset:
-            self.ctx.reset()
-        self.ctx.scan(d_iq, nbytes, encoding, base_position=base_position,
-                      n_owned=n_owned)
+        with self._failing():
+            if reset:
+                self.ctx.reset()
+            self.ctx.scan(d_iq, nbytes, encoding, base_position=base_position,
+                          n_owned=n_owned)
 
     def exchange(self):
         ctx, world = self.ctx, self.world
-        with self._on_stream():
+        with self._failing(), self._on_stream():
             ctx.export_block(self.d_blk, self.block)
             if self.stage_exchange:
                 self.h_blk.copy_(self.d_blk, non_blocking=True)
@@ -257,7 +279,7 @@ class ShardedDecoder:
     def finish(self):
         """Total number of frames (all ranks); on rank 0, frames() returns them in
         position order (valid until this decoder's next begin())."""
-        with self._on_stream():
+        with self._failing(), self._on_stream():
             if self.gather == "shm":
                 return self._finish_shm()
             return self._finish_collective()

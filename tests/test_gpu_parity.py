@@ -83,7 +83,11 @@ def test_mixed_traffic_all_fields(seed):
 
 
 @pytest.mark.parametrize("n", [0, 1, 17, 239, 240, 241, 255, 16128 + 239, 16128 + 240,
-                               16367, 16368, 16384, 2 * 16128 + 238])
+                               16367, 16368, 16384, 2 * 16128 + 238,
+                               # the default kernel's 7808-position tiles (8064 samples read)
+                               7807, 7808, 7808 + 238, 7808 + 239, 7808 + 240, 7808 + 241,
+                               8063, 8064, 8065, 2 * 7808 + 238, 2 * 7808 + 239,
+                               2 * 7808 + 240, 3 * 7808 - 1 + 240])
 def test_edge_lengths(n):
     rng = np.random.default_rng(n)
     raw = rng.integers(0, 256, size=2 * n, dtype=np.uint8).tobytes()
@@ -266,6 +270,48 @@ def test_overflow_reruns_the_chunk(small, emit):
         assert_same_frames(frames_as_dicts(ctx.collect()), want)
 
 
+def test_frame_list_regrow_keeps_the_record_list():
+    """Only the accepted / frame lists too small, with a record list of tens of
+    megabytes: the records stay where the scan wrote them and only the resolve
+    runs again on new accepted lists.  (Until round 3 every list was replaced
+    and the scan was NOT run again, so that the filter read a record buffer fresh
+    from hipMalloc; small buffers came back from the allocator with their old
+    contents and hid it.)"""
+    import torch
+    p = synth.default_params(2, n_samples=80000000, mean_gap=20000, reply_permille=200,
+                             unknown_permille=200, n_icao=9, seed=77)
+    fr = synth.make_frames(p)
+    n = p.n_samples
+    d = torch.empty(2 * n + 16, dtype=torch.uint8, device="cuda")
+    synth.fill_device(d.data_ptr(), n, p.encoding, p.seed, fr)
+    with AdsbContext(n) as ctx:                          # lists that hold everything
+        ctx.submit_device(d, 2 * n, ENC_UC8)
+        want = ctx.collect()
+        assert ctx.list_regrows() == 0
+    assert len(want) > 2000
+    for emit in (EMIT_ACCEPTED,):
+        # 5 M record slots of 8 bytes = 40 MB; 16 frames
+        with AdsbContext(n, emit_mode=emit, max_frames=16) as ctx:
+            # other allocations in between, so that a freed list is not handed back
+            junk = [torch.full((8 << 20,), 0x5a, dtype=torch.uint8, device="cuda")
+                    for _ in range(4)]
+            ctx.submit_device(d, 2 * n, ENC_UC8)
+            got = ctx.collect()
+            assert 1 <= ctx.list_regrows() <= 3
+            del junk
+        assert got.tobytes() == want.tobytes()
+    # a window of it against the oracle
+    lo, m = 30000000, 2000000
+    raw = d[2 * lo:2 * (lo + m)].cpu().numpy().tobytes()
+    ps = ob.PlaneSet()
+    pos = want["position"].astype(np.int64)
+    for f in want[pos < lo]:
+        if int(f["flags"]) & sora_amd.FRAME_SQUITTER:
+            ps.parse(sora_amd.bits_to_string(f["bits"]))
+    ref = [c for c in ob.scan(raw, base_position=lo, plane_set=ps) if c["accepted"]]
+    assert_same_frames(frames_as_dicts(want[(pos >= lo) & (pos < lo + m - 239)]), ref)
+
+
 def test_overflow_reruns_a_streamed_block():
     """The same through sora_adsb_stream_*: the pinned frame buffers follow."""
     p = synth.default_params(2, n_samples=500000, mean_gap=300, reply_permille=300,
@@ -433,6 +479,31 @@ def test_sc16_config4_traffic():
     acc, _ = gpu_frames(raw, ENC_SC16, emit=EMIT_ACCEPTED, host=True)
     assert_same_frames(acc, [c for c in want if c["accepted"]])
     assert len(acc) > 1000
+
+
+@pytest.mark.parametrize("emit", [EMIT_ACCEPTED, EMIT_CANDIDATES])
+def test_sc16_config4_traffic_with_correction(emit):
+    """BASELINE configs[3] as it reads: dense overlapping sc16 traffic, 20 % of the
+    frames with one flipped bit, AND the correction path on -- against the oracle
+    (parity unpinned by the reference, which never corrects and has no sc16 route:
+    the oracle restates this build's definitions), whole and through the streaming
+    ingest."""
+    p = synth.default_params(4, n_samples=1300000, seed=15, reply_permille=150,
+                             unknown_permille=300)
+    raw = synth.fill_host(p.n_samples, p.encoding, p.seed, synth.make_frames(p)).tobytes()
+    want = ob.scan(raw, ENC_SC16, correct=True)
+    assert sum(1 for c in want if c["corrected_bit"] >= 0) > 200
+    if emit == EMIT_ACCEPTED:
+        want = [c for c in want if c["accepted"]]
+    assert sum(1 for c in want if c["accepted"] and c["df"] not in (11, 17, 18)) > 10
+    got, counts = gpu_frames(raw, ENC_SC16, emit=emit, correct_single_bit=True)
+    assert_same_frames(got, want)
+    n = p.n_samples
+    with AdsbContext(300000 + 239, emit_mode=emit, max_candidates=n // 2, max_squitters=n // 2,
+                     correct_single_bit=True) as ctx:
+        parts = list(ctx.stream(raw, ENC_SC16, 300000))
+    assert len(parts) == 5
+    assert_same_frames(frames_as_dicts(np.concatenate(parts)), want)
 
 
 def test_sc16_frames_on_tile_edges():
@@ -855,10 +926,11 @@ def test_scan_variants_noise_dense_hits_and_correction(monkeypatch, variant, enc
 
 @pytest.mark.parametrize("variant", [0, 1])
 def test_long_scan_regions(monkeypatch, variant):
-    """A candidate record carries its position relative to the first tile of its
-    workgroup's range in 22 bits (6 in the key, 16 in the tail).  One workgroup
-    for the whole capture makes every bit of that matter; a range too long for
-    22 bits is refused, not wrapped."""
+    """One workgroup for the whole capture: the longest range of tiles a scan
+    region can be.  A candidate record carries its position within its TILE (6
+    bits in the key, 8 in the tail); which tile, the filter finds in the range's
+    tile_end[] slice, which it keeps in LDS -- SORA_RANGE_TILES_MAX slots, which is
+    what limits a range (the scan refuses a longer one, it does not wrap)."""
     monkeypatch.setenv("SORA_ADSB_SCAN_VARIANT", str(variant))
     monkeypatch.setenv("SORA_ADSB_SCAN_MIN_TILES", "1000000")
     p = synth.default_params(2, n_samples=3000000, mean_gap=3000, reply_permille=200,
@@ -878,3 +950,129 @@ def test_long_scan_regions(monkeypatch, variant):
         with pytest.raises(sora_amd.SoraError) as e:
             ctx.submit_device(buf, 2 * n, ENC_UC8)
         assert "too long" in str(e.value)
+
+
+def test_randomized_parity_slice():
+    """A seeded slice of tools/fuzz_parity.py in the driver's tier: captures of
+    random length, density, encoding, emit mode and scan geometry, lists that have
+    to grow, a dense stretch somewhere -- each against the oracle, every field."""
+    import os
+    rng = np.random.default_rng(20261111)
+    dense7 = np.array([9, 1, 8, 1, 2, 2, 2], dtype=np.int64)
+    saved = {k: os.environ.get(k) for k in ("SORA_ADSB_SCAN_ROUNDS", "SORA_ADSB_SCAN_MIN_TILES")}
+    try:
+        for case in range(60):
+            enc = [ENC_UC8, ENC_UC8, ENC_SC8, ENC_SC16][rng.integers(0, 4)]
+            n = int(rng.choice([rng.integers(240, 3000), rng.integers(3000, 100000),
+                                rng.integers(100000, 600000)]))
+            gap = int(rng.choice([60, 300, 1500, 6000]))
+            p = synth.default_params(4 if enc == ENC_SC16 else 2, n_samples=n, mean_gap=gap,
+                                     reply_permille=int(rng.integers(0, 500)),
+                                     unknown_permille=int(rng.integers(0, 500)),
+                                     n_icao=int(rng.integers(1, 40)),
+                                     seed=int(rng.integers(1, 1 << 30)))
+            p.encoding = enc
+            raw = synth.fill_host(p.n_samples, enc, p.seed, synth.make_frames(p)).tobytes()
+            if enc != ENC_SC16 and rng.integers(0, 4) == 0:
+                m = int(rng.integers(1000, 30000))
+                iq = np.full(2 * m, 128, dtype=np.uint8)
+                iq[0::2] = 128 + 10 * dense7[np.arange(m) % 7]
+                if enc == ENC_SC8:
+                    iq = (iq.astype(np.int16) - 128).astype(np.int8).view(np.uint8)
+                at = int(rng.integers(0, n)) * 2
+                raw = raw[:at] + iq.tobytes() + raw[at:]
+                n = len(raw) // 2
+            os.environ["SORA_ADSB_SCAN_ROUNDS"] = str(int(rng.choice([1, 2, 16, 32, 64])))
+            os.environ["SORA_ADSB_SCAN_MIN_TILES"] = str(int(rng.choice([1, 2, 8, 50])))
+            emit = [EMIT_ACCEPTED, EMIT_CANDIDATES][rng.integers(0, 2)]
+            fix = bool(rng.integers(0, 4) == 0)
+            small = rng.integers(0, 3) == 0
+            kw = dict(max_candidates=64, max_squitters=64, max_frames=64) if small else \
+                dict(max_candidates=n // 2 + 1024, max_squitters=n // 2 + 1024)
+            want = ob.scan(raw, enc, correct=fix)
+            if emit == EMIT_ACCEPTED:
+                want = [c for c in want if c["accepted"]]
+            with AdsbContext(max(n, 1), emit_mode=emit, correct_single_bit=fix, **kw) as ctx:
+                ctx.submit_host(raw, enc)
+                got = frames_as_dicts(ctx.collect())
+            try:
+                assert_same_frames(got, want)
+            except AssertionError as e:
+                raise AssertionError(f"case {case}: enc {enc} n {n} gap {gap} emit {emit} "
+                                     f"fix {fix} small {small} seed {p.seed}: {e}") from None
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def test_regrow_cases_on_poisoned_lists():
+    """The list-regrow tests once more on the -DSORA_POISON_LISTS build of the
+    library (`make -C sora_amd/csrc poison`): every list comes out of hipMalloc
+    filled with 0xa5, so a kernel that reads a list nothing has written since
+    produces frames that differ instead of passing on what the allocator left."""
+    import os
+    import subprocess
+    import sys
+    lib = os.path.join(os.path.dirname(sora_amd.__file__), "lib", "libsora_adsb_gpu_poison.so")
+    if not os.path.exists(lib) or os.environ.get("SORA_ADSB_LIB"):
+        pytest.skip("no poisoned build (or already running on one)")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", __file__,
+                        "-k", "overflow_reruns or regrow_keeps or record_ring",
+                        "--timeout", "300", "--timeout-method", "thread", "-p", "no:cacheprovider"],
+                       env=dict(os.environ, SORA_ADSB_LIB=lib), capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert " passed" in r.stdout
+
+
+def test_two_contexts_scan_stream_and_resolve_streams():
+    """sora_adsb_set_resolve_stream: two contexts take turns on ONE scan stream,
+    each with a resolve stream of its own (bench.py --schedule two-stream): a
+    context's calls keep their order across its two streams -- scan, squitter
+    export, add_known, resolve, collect, then the reset and the scan of its next
+    capture -- while the other context's scan runs beside its resolve.  Different
+    captures alternate so that a result taken from the wrong scan would show."""
+    import torch
+    caps = []
+    for seed in (11, 12, 13):
+        p = synth.default_params(2, n_samples=700000 + 1000 * seed, mean_gap=600,
+                                 reply_permille=300, unknown_permille=200, n_icao=6, seed=seed)
+        raw = synth.fill_host(p.n_samples, p.encoding, p.seed, synth.make_frames(p)).tobytes()
+        d = torch.from_numpy(np.frombuffer(raw + bytes(16), dtype=np.uint8).copy()).cuda()
+        caps.append((d, len(raw), [c for c in ob.scan(raw) if c["accepted"]]))
+    scan_stream = torch.cuda.Stream()
+    rstreams = [torch.cuda.Stream(priority=-1) for _ in range(2)]
+    ctxs = [AdsbContext(720000, stream=scan_stream.cuda_stream,
+                        resolve_stream=rs.cuda_stream, max_squitters=100000)
+            for rs in rstreams]
+    torch.cuda.synchronize()
+    pending = None
+    for i in range(9):
+        ctx = ctxs[i % 2]
+        d, nbytes, want = caps[i % 3]
+        ctx.reset()
+        ctx.scan(d, nbytes, ENC_UC8)
+        ctx.resolve()
+        if pending is not None:
+            pctx, pwant = pending
+            assert_same_frames(frames_as_dicts(pctx.collect()), pwant)
+        pending = (ctx, want)
+    pctx, pwant = pending
+    assert_same_frames(frames_as_dicts(pctx.collect()), pwant)
+    # back on one stream: the same context, the same answer
+    ctxs[0].set_resolve_stream(None)
+    d, nbytes, want = caps[1]
+    ctxs[0].reset()
+    ctxs[0].submit_device(d, nbytes, ENC_UC8)
+    assert_same_frames(frames_as_dicts(ctxs[0].collect()), want)
+    # streaming ingest with a resolve stream set
+    ctxs[1].set_resolve_stream(rstreams[1].cuda_stream)
+    ctxs[1].reset()
+    raw = caps[2][0][:caps[2][1]].cpu().numpy().tobytes()
+    got = frames_as_dicts(np.concatenate(list(ctxs[1].stream(raw, ENC_UC8, 200000))))
+    assert_same_frames(got, caps[2][2])
+    for c in ctxs:
+        c.close()

@@ -161,6 +161,17 @@ def _worker(rank, world, port, raw, result_path, gather, exchange_records=64, gp
         dist.destroy_process_group()
 
 
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _same_as_oracle(got, want):
+    from conftest import assert_same_frames, frames_as_dicts
+    assert_same_frames(frames_as_dicts(got), want)
+
+
 def test_plan_shards():
     plan = plan_shards(1000003, 4)
     assert sum(p[1] for p in plan) == 1000003
@@ -234,17 +245,96 @@ def test_exchange_block_overflow_is_reported(tmp_path):
     assert os.path.exists(out + ".0.raised") and os.path.exists(out + ".1.raised")
 
 
+def _failing_worker(rank, world, port, raw, path):
+    """Rank 1's context fails when its frames are asked for; rank 0 must not spin
+    until the timeout."""
+    import time
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        total = len(raw) // 2
+        first, owned, local = plan_shards(total, world)[rank]
+        shard = torch.frombuffer(bytearray(raw[2 * first:2 * (first + local)] + bytes(16)),
+                                 dtype=torch.uint8)
+        ctx = OracleContext()
+        if rank == 1:
+            def boom(*_a):
+                raise RuntimeError("7 frames exceed max_frames")
+            ctx.collect_device = boom
+        dec = ShardedDecoder(ctx, rank, world, torch.device("cpu"), 20000, gather="shm")
+        dec.begin(shard, 2 * local, ob.ENC_UC8, first, owned)
+        dec.exchange()
+        t0 = time.monotonic()
+        try:
+            dec.finish()
+            msg = "no error"
+        except RuntimeError as e:
+            msg = str(e)
+        with open(f"{path}.{rank}", "w") as fh:
+            fh.write(f"{time.monotonic() - t0:.3f}\n{msg}")
+        dec.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_a_failing_rank_fails_the_others_at_once(tmp_path):
+    """An error on one rank between begin() and finish() is marked in the shared
+    header; the ranks waiting for that rank's frames raise within a second
+    instead of spinning for SPIN_TIMEOUT_S."""
+    p = synth.default_params(2, n_samples=120000, mean_gap=900, n_icao=4, seed=8)
+    raw = synth.fill_host(p.n_samples, p.encoding, p.seed, synth.make_frames(p)).tobytes()
+    out = str(tmp_path / "fail")
+    mp.spawn(_failing_worker, args=(2, _free_port(), raw, out), nprocs=2, join=True)
+    t1, msg1 = open(out + ".1").read().split("\n", 1)
+    assert "exceed max_frames" in msg1
+    t0, msg0 = open(out + ".0").read().split("\n", 1)
+    assert "rank 1 failed" in msg0 and float(t0) < 5.0
+
+
+def four_shard_capture():
+    """800 k samples for four ranks with the stateful rule crossing shard edges
+    both ways: address A squitters first in shard 0 and is replied to in shards 0
+    (before: rejected), 1 and 3 (accepted); address B squitters first in shard 2 and
+    has replies in shards 0, 1 and early in shard 2 (all rejected: plane.c:479-483
+    knows B only from its squitter on) and later in shards 2 and 3 (accepted)."""
+    A, B = 0x4840D6, 0xABC123
+    sq = lambda icao, me: synth.build_df17(icao, me)            # noqa: E731
+    rp = lambda icao, k: synth.build_short_reply(4, 0x123400 + k, icao)     # noqa: E731
+    rows = [
+        (10000, rp(A, 1), 70, 0, 56),       # before A's first squitter: rejected
+        (50000, sq(A, 0x58B986D0B3BD25), 70, 0, 112),
+        (60000, rp(A, 2), 70, 0, 56),       # shard 0, accepted
+        (120000, rp(B, 3), 70, 0, 56),      # B unknown yet: rejected
+        (250000, rp(A, 4), 70, 0, 56),      # shard 1: A known from shard 0
+        (300000, rp(B, 5), 70, 0, 56),      # shard 1: B is first seen in shard 2: rejected
+        (420000, rp(B, 6), 70, 0, 56),      # shard 2, before B's squitter: rejected
+        (450000, sq(B, 0x99440994083817), 70, 0, 112),
+        (480000, rp(B, 7), 70, 0, 56),      # shard 2, accepted
+        (520000, sq(A, 0x58B986D0B3BD25), 70, 0, 112),   # a later squitter of A changes nothing
+        (650000, rp(A, 8), 70, 0, 56),      # shard 3: A from shard 0
+        (700000, rp(B, 9), 70, 0, 56),      # shard 3: B from shard 2
+        (799000, synth.build_long_reply(20, 0x0a1b2c, 0x11223344556677, A), 70, 0, 112),
+    ]
+    raw = synth.fill_host(800000, ob.ENC_UC8, 4242, synth.frame_table(rows)).tobytes()
+    want = [c for c in ob.scan(raw) if c["accepted"]]
+    got = {c["position"] for c in want}
+    assert {50000, 60000, 250000, 450000, 480000, 520000, 650000, 700000, 799000} <= got
+    assert not ({10000, 120000, 300000, 420000} & got)
+    return raw, want
+
+
+@pytest.mark.timeout(300)
+def test_four_ranks_first_seen_crosses_two_boundaries(tmp_path):
+    raw, want = four_shard_capture()
+    assert [p[0] for p in plan_shards(len(raw) // 2, 4)] == [0, 200000, 400000, 600000]
+    out = str(tmp_path / "frames.npy")
+    mp.spawn(_worker, args=(4, _free_port(), raw, out, "shm"), nprocs=4, join=True)
+    _same_as_oracle(np.load(out), want)
+
+
 # ---- GPU tier: two processes, real contexts, one device ----------------------
-
-def _free_port():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
-
-
-def _same_as_oracle(got, want):
-    from conftest import assert_same_frames, frames_as_dicts
-    assert_same_frames(frames_as_dicts(got), want)
 
 
 @pytest.mark.gpu
@@ -289,3 +379,16 @@ def test_two_gpu_processes_small_lists_and_block_overflow(tmp_path):
     out2 = str(tmp_path / "frames2.npy")
     mp.spawn(_overflow_worker, args=(2, _free_port(), raw, out2, True), nprocs=2, join=True)
     assert os.path.exists(out2 + ".0.raised") and os.path.exists(out2 + ".1.raised")
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("gather", ["shm", "collective"])
+def test_four_gpu_processes_first_seen_crosses_two_boundaries(tmp_path, gather):
+    """World 4 on the one GPU (four processes, eight contexts): an address first
+    seen in shard 0 with replies in shard 3, and one first seen in shard 2 whose
+    earlier replies in shards 0-2 stay rejected; bit-exact with the oracle."""
+    raw, want = four_shard_capture()
+    out = str(tmp_path / "frames.npy")
+    mp.spawn(_worker, args=(4, _free_port(), raw, out, gather, 64, True), nprocs=4, join=True)
+    _same_as_oracle(np.load(out), want)

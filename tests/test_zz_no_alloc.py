@@ -161,3 +161,49 @@ def test_noalloc_limits_are_errors_or_flags():
     got, total, flags = noalloc(d_iq, 2 * n, ENC_UC8, d_many, d_status, emit=EMIT_CANDIDATES)
     assert flags == 0 and total == len(got) == (n - 239 + 9) // 10
     assert np.array_equal(got["position"], np.arange(total, dtype=np.uint64) * 10)
+
+
+# ---- the header's claims beyond parity: it allocates nothing, leaves the
+# caller's current device alone, and can be captured into a HIP graph and replayed
+def test_noalloc_allocates_nothing_and_replays_from_a_graph():
+    import torch
+    raw_a, raw_b = traffic(800000, 71), traffic(800000, 72)
+    want_a, want_b = by_context(raw_a, ENC_UC8), by_context(raw_b, ENC_UC8)
+    assert len(want_a) > 100 and want_a.tobytes() != want_b.tobytes()
+    d_iq = torch.frombuffer(bytearray(raw_a + bytes(16)), dtype=torch.uint8).cuda()
+    d_b = torch.frombuffer(bytearray(raw_b + bytes(16)), dtype=torch.uint8).cuda()
+    d_frames = torch.zeros(100000 * FRAME_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+    d_status = torch.zeros(2, dtype=torch.int64, device="cuda")
+    # the first call on the device looks the array up: outside any capture
+    got, _, flags = noalloc(d_iq, len(raw_a), ENC_UC8, d_frames, d_status)
+    assert flags == 0 and got.tobytes() == want_a.tobytes()
+    assert torch.cuda.current_device() == 0
+    # free device memory as the driver sees it: unchanged by further calls
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(3):
+        noalloc(d_iq, len(raw_a), ENC_UC8, d_frames, d_status)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free1 == free0
+    # captured into a graph on a side stream, replayed twice with different input
+    # in the same buffer: the replay reads what the buffer holds then
+    s = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    d_frames.zero_()
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g, stream=s):
+        rc = lib().sora_adsb_decode_noalloc(0, torch.cuda.current_stream().cuda_stream,
+                                            d_iq.data_ptr(), len(raw_a), ENC_UC8, 0,
+                                            len(raw_a) // 2, EMIT_ACCEPTED, 0, 0,
+                                            d_frames.data_ptr(), 100000, d_status.data_ptr())
+        assert rc == 0
+    torch.cuda.synchronize()
+    assert int(d_status.cpu()[0]) != len(want_b)         # the capture ran nothing yet
+    for raw, want in ((raw_b, want_b), (raw_a, want_a)):
+        d_iq.copy_(torch.frombuffer(bytearray(raw + bytes(16)), dtype=torch.uint8))
+        g.replay()
+        torch.cuda.synchronize()
+        total, flags = (int(x) for x in d_status.cpu().numpy().view(np.uint64))
+        frames = d_frames.cpu().numpy().view(FRAME_DTYPE)[:total]
+        assert flags == 0 and frames.tobytes() == want.tobytes()
