@@ -329,7 +329,7 @@ const char *sora_adsb_scan_kernel_name(const sora_adsb_ctx *ctx, int encoding);
  * 4096-float ring and a malloc'ed list of in-flight messages,
  * plane-iq.c:22-56) and none among the reference's callers; it exists for those
  * callers alone.  It needs no context: every list the kernels use lives in one
- * static device array of the library, SORA_NOALLOC_SCRATCH_BYTES (38 MiB) per
+ * static device array of the library, SORA_NOALLOC_SCRATCH_BYTES (42 MiB) per
  * GPU the entry point has run on, held until the process ends.  The call
  * allocates nothing, frees nothing and never waits: it queues its kernels on
  * `stream` (a hipStream_t; NULL = the null stream) and returns.
@@ -353,7 +353,7 @@ const char *sora_adsb_scan_kernel_name(const sora_adsb_ctx *ctx, int encoding);
  * make it outside a graph capture (nbytes = 0 will do).
  */
 #define SORA_NOALLOC_MAX_SAMPLES	(1u << 21)
-#define SORA_NOALLOC_SCRATCH_BYTES	(38u << 20)
+#define SORA_NOALLOC_SCRATCH_BYTES	(42u << 20)
 #define SORA_NOALLOC_MAX_ADDRESSES	65536	/* distinct known addresses */
 #define SORA_NOALLOC_RECORDS_FULL	0x01	/* cannot happen; checked all the same */
 #define SORA_NOALLOC_SQUITTERS_FULL	0x02	/* > 2^18 clean squitters in the chunk */

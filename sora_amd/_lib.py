@@ -29,7 +29,7 @@ OPT_FIXED_LISTS = 2
 OPT_WIRE_FRAMES = 4
 WINDOW, HALO = 240, 239
 NOALLOC_MAX_SAMPLES = 1 << 21
-NOALLOC_SCRATCH_BYTES = 38 << 20
+NOALLOC_SCRATCH_BYTES = 42 << 20
 
 
 class SoraError(RuntimeError):

@@ -48,6 +48,12 @@ struct sora_scan_args {
     uint8_t *tail;		/* [groups][rec_cap] */
     uint32_t *tile_end;		/* [n_tiles] */
     uint64_t *sq;		/* [groups][sq_cap] clean squitters */
+    /* [groups][sq_cap][4]: the 112 message bits of each of them as phase 4
+     * sliced them (MSB first, sora_candidate::bits), so that finalize need not
+     * slice them again from 224 samples: the candidate record of a clean (or
+     * corrected) squitter carries its index in this list where a reply's carries
+     * its address */
+    uint32_t *sq_bits;
     uint32_t rec_cap, sq_cap;	/* per-group capacities */
     uint32_t *rec_count;	/* [groups] records produced (may exceed cap) */
     uint32_t *sq_count;		/* [groups] */
@@ -80,6 +86,7 @@ struct sora_resolve_args {
     const uint32_t *rec_count;
     uint32_t rec_cap;
     const uint64_t *sq;
+    const uint32_t *sq_bits;	/* see sora_scan_args */
     const uint32_t *sq_count;
     uint32_t sq_cap;
     uint64_t *first_seen;	/* [1 << 24] smallest global position, or ~0

@@ -264,6 +264,7 @@ adsb_scan_kernel(sora_scan_args a) {
     uint32_t *key_out = a.key + (uint64_t) group * a.rec_cap;
     uint8_t *tail_out = a.tail + (uint64_t) group * a.rec_cap;
     uint64_t *sq_out = a.sq + (uint64_t) group * a.sq_cap;
+    u32x4 *sq_bits_out = reinterpret_cast<u32x4 *>(a.sq_bits) + (uint64_t) group * a.sq_cap;
     uint32_t n_rec = 0;			/* workgroup-uniform */
     if (tid == 0)
 	s_sq_total = 0;			/* visible behind the first tile's barriers */
@@ -491,17 +492,22 @@ adsb_scan_kernel(sora_scan_args a) {
 			    payload ^= 1u << (31 - b);
 		    }
 		}
-		/* key and tail (sora_scan_args); the full record only for the
-		 * squitter list */
-		const uint32_t idx = n_rec + i;
-		if (idx < a.rec_cap) {
-		    key_out[idx] = payload | ((uint32_t) kind << 24) | ((q >> 8) << 26);
-		    tail_out[idx] = (uint8_t) q;
-		}
+		/* the full record, and the bits, only for the squitter list: its
+		 * candidate record names the list entry instead of the address */
+		uint32_t word = payload;
 		if (kind == SORA_REC_KIND_SQUITTER || kind == SORA_REC_KIND_CORRECTED) {
 		    const uint32_t k = atomicAdd(&s_sq_total, 1u);
-		    if (k < a.sq_cap)
+		    if (k < a.sq_cap) {
 			sq_out[k] = sora_rec_make(kind, tile_start + q, payload);
+			sq_bits_out[k] = u32x4{c.bits[0], c.bits[1], c.bits[2], c.bits[3]};
+		    }
+		    word = k & 0xffffffu;
+		}
+		/* key and tail (sora_scan_args) */
+		const uint32_t idx = n_rec + i;
+		if (idx < a.rec_cap) {
+		    key_out[idx] = word | ((uint32_t) kind << 24) | ((q >> 8) << 26);
+		    tail_out[idx] = (uint8_t) q;
 		}
 		/* wave-uniform counts: ballots land in SGPRs, off the VALU */
 		st_sq += (uint32_t) __popcll(__ballot(kind == SORA_REC_KIND_SQUITTER));
@@ -611,7 +617,7 @@ next_lane(uint32_t v) {
 constexpr uint32_t kStageUnit = 1024;		/* records per flush: four per thread */
 constexpr uint32_t kStageRing = 2 * kStageUnit;	/* a unit being filled behind one being written */
 constexpr uint32_t kStagePass = 512;		/* records staged between two flushes, at most */
-constexpr int kSqLds = 128;		/* clean squitters a workgroup keeps in LDS */
+constexpr int kSqLds = 64;		/* clean squitters a workgroup keeps in LDS (record + bits) */
 
 template <int kThreads>
 __global__ void __launch_bounds__(kThreads, SORA_DIRECT_WAVES)
@@ -632,11 +638,13 @@ adsb_scan_direct_kernel(sora_scan_args a) {
     __shared__ uint16_t s_queue[kQueueCap];
     __shared__ uint32_t s_cum[2][kWaves + 1];	/* by tile parity, see below */
     __shared__ uint32_t s_sq_total;
-    /* the workgroup's clean squitters (about sixty per range of the 1-hour
-     * capture): kept here and written out as the workgroup ends, so that the
-     * tile loop issues no store that only some tiles have (see the tile loop);
-     * those beyond kSqLds go straight to the global list */
+    /* the workgroup's clean squitters (about forty per range of the 1-hour
+     * capture) and their message bits: kept here and written out as the
+     * workgroup ends, so that the tile loop issues no store that only some tiles
+     * have (see the tile loop); those beyond kSqLds go straight to the global
+     * lists */
     __shared__ uint64_t s_sq[kSqLds];
+    __shared__ __attribute__((aligned(16))) u32x4 s_sq_bits[kSqLds];
     /* the records on their way out: slot n of the region at n mod kStageRing */
     __shared__ __attribute__((aligned(16))) uint32_t s_stage_key[kStageRing];
     __shared__ __attribute__((aligned(16))) uint8_t s_stage_tail[kStageRing];
@@ -652,6 +660,7 @@ adsb_scan_direct_kernel(sora_scan_args a) {
     const uint64_t tile_end = a.n_tiles * (group + 1) / groups;
 
     uint64_t *sq_out = a.sq + (uint64_t) group * a.sq_cap;
+    u32x4 *sq_bits_out = reinterpret_cast<u32x4 *>(a.sq_bits) + (uint64_t) group * a.sq_cap;
     uint32_t n_rec = 0;		/* records so far (counted on past the region's end) */
     uint32_t n_flushed = 0;	/* ... of which written out: a multiple of kStageUnit */
     uint32_t st_cand = 0, st_sq = 0, st_dirty = 0, st_fixed = 0;
@@ -864,16 +873,24 @@ adsb_scan_direct_kernel(sora_scan_args a) {
 			payload ^= 1u << (31 - b);
 		}
 	    }
-	    *key = payload | (kind << 24) | ((q >> 8) << 26);
-	    *tail = q;
+	    uint32_t word = payload;
 	    if (kind == SORA_REC_KIND_SQUITTER || kind == SORA_REC_KIND_CORRECTED) {
+		/* into the squitter list with its bits; the candidate record
+		 * names the list entry instead of the address */
 		const uint32_t k = atomicAdd(&s_sq_total, 1u);
 		const uint64_t r = sora_rec_make(kind, tile_start + q, payload);
-		if (k < (uint32_t) kSqLds)
+		const u32x4 b4 = {c.bits[0], c.bits[1], c.bits[2], c.bits[3]};
+		if (k < (uint32_t) kSqLds) {
 		    s_sq[k] = r;
-		else if (k < a.sq_cap)
+		    s_sq_bits[k] = b4;
+		} else if (k < a.sq_cap) {
 		    sq_out[k] = r;
+		    sq_bits_out[k] = b4;
+		}
+		word = k & 0xffffffu;
 	    }
+	    *key = word | (kind << 24) | ((q >> 8) << 26);
+	    *tail = q;
 	    st_sq += (uint32_t) __popcll(__ballot(kind == SORA_REC_KIND_SQUITTER));
 	    st_dirty += (uint32_t) __popcll(__ballot(kind == SORA_REC_KIND_DIRTY));
 	    if (a.correct)
@@ -996,6 +1013,7 @@ adsb_scan_direct_kernel(sora_scan_args a) {
 	    if (i < (uint32_t) kSqLds) {
 		r = s_sq[i];
 		sq_out[i] = r;
+		sq_bits_out[i] = s_sq_bits[i];
 	    } else {
 		r = __hip_atomic_load(&sq_out[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	    }
@@ -1530,23 +1548,59 @@ template <bool kWide> struct frame_part {
     uint32_t w[kWide? 2 * kFramePairs : kFramePairs];
 };
 
+/* `given`: the frame's bits are known (a squitter: the scan kept them), only the
+ * amplitude is wanted: the 112 samples of bits 0..55, pairs j < 4 */
 template <bool kWide> __device__ __forceinline__ frame_part<kWide>
-load_frame_part(const uint8_t *iq, uint64_t p, uint32_t sub) {
+load_frame_part(const uint8_t *iq, uint64_t p, uint32_t sub, bool given) {
     frame_part<kWide> f;
     if constexpr (kWide) {
 	const uint32_t *src = reinterpret_cast<const uint32_t *>(iq) + (p + 16) + 2 * sub;
 #pragma unroll
 	for (int j = 0; j < kFramePairs; j++) {
-	    f.w[2 * j] = src[32 * j];
-	    f.w[2 * j + 1] = src[32 * j + 1];
+	    f.w[2 * j] = f.w[2 * j + 1] = 0;
+	    if (j < 4 || !given) {
+		f.w[2 * j] = src[32 * j];
+		f.w[2 * j + 1] = src[32 * j + 1];
+	    }
 	}
     } else {
 	const u32_a2 *src = reinterpret_cast<const u32_a2 *>(iq + 2 * (p + 16)) + sub;
 #pragma unroll
-	for (int j = 0; j < kFramePairs; j++)
-	    f.w[j] = src[16 * j];
+	for (int j = 0; j < kFramePairs; j++) {
+	    f.w[j] = 0;
+	    if (j < 4 || !given)
+		f.w[j] = src[16 * j];
+	}
     }
     return f;
+}
+
+/*
+ * The bits the scan kept for a clean or corrected squitter (sora_scan_args::
+ * sq_bits), as this lane's seven: bit j of the result is message bit 16 j + sub.
+ * The record names the entry within its scan region's list; the region is the
+ * one whose tile range holds the position (the quotients are exact in double:
+ * positions stay below 2^36, tiles * groups below 2^41, and a quotient that is
+ * not an integer is further from one than a double rounds).
+ */
+__device__ __forceinline__ uint64_t
+squitter_entry(const sora_resolve_args &a, uint64_t r) {
+    const uint64_t tile = (uint64_t) ((double) sora_rec_pos(r) / (double) a.tile_pos);
+    const uint64_t group = (uint64_t) ((double) ((tile + 1) * a.groups - 1) / (double) a.n_tiles);
+    const uint32_t k = sora_rec_addr(r);
+    if (group >= a.groups || k >= a.sq_cap)
+	return 0;				/* not reached: such a scan is run again */
+    return group * a.sq_cap + k;
+}
+
+__device__ __forceinline__ uint32_t
+load_given_bits(const sora_resolve_args &a, uint64_t r, uint32_t sub) {
+    const uint32_t *w = a.sq_bits + 4 * squitter_entry(a, r);
+    uint32_t mine = 0;
+#pragma unroll
+    for (int j = 0; j < kFramePairs; j++)
+	mine |= ((w[j >> 1] >> (31 - 16 * (j & 1) - sub)) & 1u) << j;
+    return mine;
 }
 
 /* v of the lane `n` places up in this lane's row of 16, wrapping (row_ror) */
@@ -1588,6 +1642,44 @@ row_sum(double v) {
     return v;
 }
 
+/* frame f of the list, in the form the context hands out (plane.c:461-480 for
+ * the fields derived from the bits) */
+template <bool kWire> __device__ __forceinline__ void
+store_frame(const sora_resolve_args &a, uint64_t f, uint64_t r, const uint32_t bits[4],
+	uint32_t syndrome, int corrected, uint32_t sum56, double a56, uint64_t amp) {
+    const uint32_t df = bits[0] >> 27;
+    const bool is_long = df >= 16 && df <= 24;
+    const bool squitter = df == 11 || df == 17 || df == 18;
+    const uint64_t pos = a.base_position + sora_rec_pos(r);
+    const uint32_t flags = (is_long? SORA_FRAME_LONG : 0) |
+	    (squitter? SORA_FRAME_SQUITTER : 0) |
+	    (corrected >= 0? SORA_FRAME_CORRECTED : 0) |
+	    ((sora_rec_kind(r) & SORA_REC_ACCEPTED)? SORA_FRAME_ACCEPTED : 0);
+    if constexpr (kWire) {
+	sora_adsb_wire_frame w;
+	w.bits[0] = bits[0]; w.bits[1] = bits[1]; w.bits[2] = bits[2];
+	w.bits3_cb_flags = (bits[3] & 0xffff0000u) | (((uint32_t) corrected & 0xffu) << 8) | flags;
+	w.position_lo = (uint32_t) pos;
+	w.pos_hi_amp_hi = ((uint32_t) (pos >> 32) << 24) | ((uint32_t) (amp >> 32) & 0xffffffu);
+	w.amp_lo = (uint32_t) amp;
+	reinterpret_cast<sora_adsb_wire_frame *>(a.frames)[f] = w;
+    } else {
+	sora_adsb_frame fr;
+	fr.position = pos;
+	fr.bits[0] = bits[0]; fr.bits[1] = bits[1];
+	fr.bits[2] = bits[2]; fr.bits[3] = bits[3];
+	fr.amplitude_56 = a56;
+	fr.syndrome = syndrome;
+	fr.address = squitter? (bits[0] & 0xffffffu) : syndrome;
+	fr.sum56 = sum56;
+	fr.df = (uint8_t) df;
+	fr.corrected_bit = (int8_t) corrected;
+	fr.flags = (uint8_t) flags;
+	fr.reserved = 0;
+	a.frames[f] = fr;
+    }
+}
+
 /*
  * Four frames, one per row of the wave: frame index f and record r are this
  * row's.  Every sum below is exact in any order: the 8-bit terms are integers;
@@ -1597,8 +1689,8 @@ row_sum(double v) {
  */
 template <bool kWide, bool kWire> __device__ __forceinline__ void
 finalize_four(const sora_resolve_args &a, uint64_t f, bool valid, uint64_t r,
-	const frame_part<kWide> &part, uint32_t lane, const group_powers &pw,
-	uint32_t flip, bool any_corrected) {
+	const frame_part<kWide> &part, bool given, uint32_t given_bits, uint32_t lane,
+	const group_powers &pw, uint32_t flip, bool any_corrected) {
     const uint32_t sub = lane & 15, row_shift = lane & 48;
     uint32_t chunk[kFramePairs];
     uint32_t x_long = 0, x_short = 0, sum56 = 0;
@@ -1624,6 +1716,8 @@ finalize_four(const sora_resolve_args &a, uint64_t f, bool valid, uint64_t r,
 	    if (j < 4)
 		sum56 += counts? (uint32_t) both : 0u;
 	}
+	if (given)			/* this row's frame came with its bits */
+	    nu = (given_bits >> j) & 1u;
 	const unsigned long long mask = __ballot(nu);
 	chunk[j] = (uint32_t) (mask >> row_shift) & 0xffffu;
 	if (j < 6)
@@ -1644,7 +1738,6 @@ finalize_four(const sora_resolve_args &a, uint64_t f, bool valid, uint64_t r,
     const uint32_t ap = is_long? (((bits[2] & 0xffu) << 16) | (bits[3] >> 16))
 	    : (bits[1] >> 8);
     const uint32_t syndrome = crc ^ ap;
-    const bool squitter = df == 11 || df == 17 || df == 18;
 
     /* option: the scan marked this squitter as one flipped bit away from a
      * clean one; find the bit (syndrome == x^k mod G, b = n - 1 - k) and flip
@@ -1682,41 +1775,8 @@ finalize_four(const sora_resolve_args &a, uint64_t f, bool valid, uint64_t r,
 	a56 = (double) sum56 * (1.0 / 32768.0);		/* exact: see sora_adsb_frame */
 	amp = sum56;
     }
-    if constexpr (kWire) {
-	if (valid && sub == 0) {
-	    const uint64_t pos = a.base_position + sora_rec_pos(r);
-	    const uint32_t flags = (is_long? SORA_FRAME_LONG : 0) |
-		    (squitter? SORA_FRAME_SQUITTER : 0) |
-		    (corrected >= 0? SORA_FRAME_CORRECTED : 0) |
-		    ((sora_rec_kind(r) & SORA_REC_ACCEPTED)? SORA_FRAME_ACCEPTED : 0);
-	    sora_adsb_wire_frame w;
-	    w.bits[0] = bits[0]; w.bits[1] = bits[1]; w.bits[2] = bits[2];
-	    w.bits3_cb_flags = (bits[3] & 0xffff0000u) | (((uint32_t) corrected & 0xffu) << 8) | flags;
-	    w.position_lo = (uint32_t) pos;
-	    w.pos_hi_amp_hi = ((uint32_t) (pos >> 32) << 24) | ((uint32_t) (amp >> 32) & 0xffffffu);
-	    w.amp_lo = (uint32_t) amp;
-	    reinterpret_cast<sora_adsb_wire_frame *>(a.frames)[f] = w;
-	}
-	return;
-    }
-    if (valid && sub == 0) {
-	sora_adsb_frame fr;
-	fr.position = a.base_position + sora_rec_pos(r);
-	fr.bits[0] = bits[0]; fr.bits[1] = bits[1];
-	fr.bits[2] = bits[2]; fr.bits[3] = bits[3];
-	fr.amplitude_56 = a56;
-	fr.syndrome = syndrome;
-	fr.address = squitter? (bits[0] & 0xffffffu) : syndrome;
-	fr.sum56 = sum56;
-	fr.df = (uint8_t) df;
-	fr.corrected_bit = (int8_t) corrected;
-	fr.flags = (uint8_t) ((is_long? SORA_FRAME_LONG : 0) |
-		(squitter? SORA_FRAME_SQUITTER : 0) |
-		(corrected >= 0? SORA_FRAME_CORRECTED : 0) |
-		((sora_rec_kind(r) & SORA_REC_ACCEPTED)? SORA_FRAME_ACCEPTED : 0));
-	fr.reserved = 0;
-	a.frames[f] = fr;
-    }
+    if (valid && sub == 0)
+	store_frame<kWire>(a, f, r, bits, syndrome, corrected, sum56, a56, amp);
 }
 
 /* blocks per CU of the finalize kernel: 82 VGPRs hold 5 at a time; measured
@@ -1726,6 +1786,101 @@ finalize_four(const sora_resolve_args &a, uint64_t f, bool valid, uint64_t r,
 #define SORA_FINALIZE_BLOCKS 24
 #endif
 constexpr int kFinalizeDepth = 2;	/* rounds (of four frames) whose sample fetches are in flight */
+
+/* lane i takes the value of lane i - n of its row of 16, lanes below n take 0 */
+template <int n> __device__ __forceinline__ uint32_t
+row_shift_right(uint32_t v) {
+    return (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x110 + n, 0xf, 0xf, true);
+}
+
+typedef uint32_t u32x4_a2 __attribute__((ext_vector_type(4), aligned(2)));
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+
+/*
+ * The clean squitters of a batch -- nearly every frame of a capture -- need no
+ * slicing and no CRC here: the scan kept their bits (sora_scan_args::sq_bits)
+ * and their syndrome is 0.  What is left is the amplitude (plane-iq.c:72-73), the
+ * sum over the 112 samples behind the preamble: 224 contiguous bytes (448 for
+ * sc16), 32 per lane, seven lanes of eight per frame (fourteen of sixteen for
+ * sc16), eight (four) frames per round of the wave, and a handful of
+ * instructions per frame where the slicing path (finalize_four) spends seventy.
+ * `fast`: bit i set = frame i of the batch is one of them.
+ */
+template <bool kWide, bool kWire> __device__ __forceinline__ void
+finalize_squitters(const sora_resolve_args &a, uint64_t batch, uint32_t cnt, uint64_t mine,
+	unsigned long long fast, uint32_t lane, uint32_t flip) {
+    constexpr uint32_t kLanes = kWide? 16 : 8;		/* per frame */
+    constexpr uint32_t kFrames = 64 / kLanes;		/* per round */
+    constexpr uint32_t kActive = kWide? 14 : 7;		/* lanes of a frame that load */
+    const uint32_t sub = lane % kLanes, grp = lane / kLanes;
+
+    for (uint32_t j = 0; j < cnt; j += kFrames) {
+	if (((fast >> j) & ((1ull << kFrames) - 1)) == 0)
+	    continue;					/* wave-uniform */
+	const uint32_t idx = j + grp;
+	const bool is = idx < cnt && ((fast >> idx) & 1) != 0;
+	const uint32_t k = idx < cnt? idx : cnt - 1;
+	const uint64_t r = (uint64_t) (uint32_t) __shfl((int) (uint32_t) mine, (int) k, 64) |
+		((uint64_t) (uint32_t) __shfl((int) (uint32_t) (mine >> 32), (int) k, 64) << 32);
+	const uint64_t p = sora_rec_pos(r);
+	u32x4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0}, w = {0, 0, 0, 0};
+	if (is) {
+	    w = *reinterpret_cast<const u32x4 *>(a.sq_bits + 4 * squitter_entry(a, r));
+	    if (sub < kActive) {
+		if constexpr (kWide) {
+		    const uint8_t *src = a.iq + 4 * (p + 16) + 32 * sub;
+		    s0 = *reinterpret_cast<const u32x4_a4 *>(src);
+		    s1 = *reinterpret_cast<const u32x4_a4 *>(src + 16);
+		} else {
+		    const uint8_t *src = a.iq + 2 * (p + 16) + 32 * sub;
+		    s0 = *reinterpret_cast<const u32x4_a2 *>(src);
+		    s1 = *reinterpret_cast<const u32x4_a2 *>(src + 16);
+		}
+	    }
+	}
+	const uint32_t d[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+	uint32_t sum56 = 0;
+	double a56;
+	uint64_t amp;
+	bool writer;
+	if constexpr (kWide) {
+	    /* a dword is a sample; pairs (0,1) (2,3) ...: the float sum of a pair,
+	     * accumulated in double, as finalize_four does (every term an integer) */
+	    double dsum = 0;
+#pragma unroll
+	    for (int i = 0; i < 8; i += 2) {
+		const float s = __fadd_rn(__uint_as_float(sora_mag_sc16(d[i])),
+			__uint_as_float(sora_mag_sc16(d[i + 1])));
+		dsum += (double) s;
+	    }
+	    const double total = row_sum(dsum);
+	    a56 = total * (1.0 / 2147483648.0);
+	    amp = (uint64_t) total;
+	    writer = sub == 0;
+	} else {
+	    /* a dword is a pair: I0^2 + Q0^2 + I1^2 + Q1^2 in one dot product */
+	    int acc = 0;
+#pragma unroll
+	    for (int i = 0; i < 8; i++) {
+		const uint32_t x = d[i] ^ flip;
+		acc = __builtin_amdgcn_sdot4((int) x, (int) x, acc, false);
+	    }
+	    /* the lanes that did not load hold zeros ^ flip: they are left out */
+	    uint32_t v = sub < kActive? (uint32_t) acc : 0u;
+	    v += row_shift_right<4>(v);
+	    v += row_shift_right<2>(v);
+	    v += row_shift_right<1>(v);			/* lane 7 of the eight: their sum */
+	    sum56 = v;
+	    a56 = (double) sum56 * (1.0 / 32768.0);
+	    amp = sum56;
+	    writer = sub == kLanes - 1;
+	}
+	if (is && writer) {
+	    const uint32_t bits[4] = {w[0], w[1], w[2], w[3]};
+	    store_frame<kWire>(a, batch + idx, r, bits, 0u, -1, sum56, a56, amp);
+	}
+    }
+}
 
 template <bool kWide, bool kWire>
 __global__ void __launch_bounds__(kSmall)
@@ -1754,11 +1909,21 @@ finalize_kernel(sora_resolve_args a) {
 	const uint64_t mine = lane < cnt? a.acc_flat[batch + lane] : 0;
 	const bool any_corrected =
 		__ballot(lane < cnt && (sora_rec_kind(mine) & 3) == SORA_REC_KIND_CORRECTED) != 0;
+	/* clean squitters whose bits the scan kept: the short way */
+	const unsigned long long fast = __ballot(lane < cnt && a.sq_bits != nullptr &&
+		(sora_rec_kind(mine) & 3) == SORA_REC_KIND_SQUITTER &&
+		sora_rec_pos(mine) + SORA_WINDOW <= a.n_samples);
+	if (fast != 0)
+	    finalize_squitters<kWide, kWire>(a, batch, cnt, mine, fast, lane, flip);
 
+	/* everything else is sliced from the samples, four frames a round */
 	for (uint32_t j = 0; j < cnt; j += 4 * kFinalizeDepth) {
+	    if (((~fast >> j) & ((1ull << (4 * kFinalizeDepth)) - 1) &
+		    (cnt - j >= 64? ~0ull : (1ull << (cnt - j)) - 1)) == 0)
+		continue;				/* wave-uniform: nothing left here */
 	    uint64_t r[kFinalizeDepth];
-	    uint32_t idx[kFinalizeDepth];
-	    bool sane[kFinalizeDepth];
+	    uint32_t idx[kFinalizeDepth], given_bits[kFinalizeDepth];
+	    bool sane[kFinalizeDepth], given[kFinalizeDepth];
 	    frame_part<kWide> part[kFinalizeDepth];
 #pragma unroll
 	    for (int u = 0; u < kFinalizeDepth; u++) {
@@ -1770,13 +1935,20 @@ finalize_kernel(sora_resolve_args a) {
 		 * says otherwise is corrupt, and following it would read outside
 		 * the capture: such a frame is left out */
 		sane[u] = sora_rec_pos(r[u]) + SORA_WINDOW <= a.n_samples;
-		part[u] = load_frame_part<kWide>(a.iq, sane[u]? sora_rec_pos(r[u]) : 0, sub);
+		/* a squitter's bits are in the scan's list: only the 112 samples
+		 * of its amplitude are read; a reply is sliced here */
+		const bool done = idx[u] < cnt && ((fast >> idx[u]) & 1) != 0;
+		sane[u] = sane[u] && !done;
+		given[u] = a.sq_bits != nullptr && sane[u] && (sora_rec_kind(r[u]) & 1u) != 0;
+		given_bits[u] = given[u]? load_given_bits(a, r[u], sub) : 0u;
+		part[u] = load_frame_part<kWide>(a.iq, sane[u]? sora_rec_pos(r[u]) : 0, sub,
+			given[u]);
 	    }
 #pragma unroll
 	    for (int u = 0; u < kFinalizeDepth; u++)
 		if (j + 4 * u < cnt)				/* wave-uniform */
-		    finalize_four<kWide, kWire>(a, batch + idx[u], idx[u] < cnt && sane[u], r[u],
-			    part[u], lane, pw, flip, any_corrected);
+			finalize_four<kWide, kWire>(a, batch + idx[u], idx[u] < cnt && sane[u], r[u],
+				part[u], given[u], given_bits[u], lane, pw, flip, any_corrected);
 	}
     }
 }

@@ -37,7 +37,8 @@ aligned(uint64_t n) {
 
 constexpr uint64_t kOffRec = 0;						/* 8 B per slot */
 constexpr uint64_t kOffSq = kOffRec + aligned((kRecSlots + 8) * 8);
-constexpr uint64_t kOffAcc = kOffSq + aligned(kSqSlots * 8);
+constexpr uint64_t kOffSqBits = kOffSq + aligned(kSqSlots * 8);		/* 16 B per slot */
+constexpr uint64_t kOffAcc = kOffSqBits + aligned(kSqSlots * 16);
 constexpr uint64_t kOffFlat = kOffAcc + aligned(kAccSlots * 8);
 constexpr uint64_t kOffKnown = kOffFlat + aligned(kFlatSlots * 8);	/* bitmap + fold */
 constexpr uint64_t kOffSeenVal = kOffKnown + aligned(SORA_KNOWN_WORDS * 4ull);
@@ -189,6 +190,7 @@ sora_adsb_decode_noalloc(int device, void *stream_, const void *d_iq, size_t nby
     a.tail = reinterpret_cast<uint8_t *>(a.key + kRecSlots);
     a.tile_end = reinterpret_cast<uint32_t *>(base + kOffTileEnd);
     a.sq = reinterpret_cast<uint64_t *>(base + kOffSq);
+    a.sq_bits = reinterpret_cast<uint32_t *>(base + kOffSqBits);
     a.rec_cap = region_slots(groups);
     a.sq_cap = (uint32_t) (kSqSlots / groups);
     a.rec_count = reinterpret_cast<uint32_t *>(base + kOffRecCount);
@@ -213,6 +215,7 @@ sora_adsb_decode_noalloc(int device, void *stream_, const void *d_iq, size_t nby
     r.rec_count = a.rec_count;
     r.rec_cap = a.rec_cap;
     r.sq = a.sq;
+    r.sq_bits = a.sq_bits;
     r.sq_count = a.sq_count;
     r.sq_cap = a.sq_cap;
     r.first_seen = reinterpret_cast<uint64_t *>(base + kOffSeenVal);
