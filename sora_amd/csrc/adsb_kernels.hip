@@ -1277,11 +1277,36 @@ export_first_kernel(sora_resolve_args a, uint64_t *dst, uint64_t dst_cap,
  * position P with address A is accepted iff first_seen[A] < P.  Each wave
  * takes a contiguous part of one scan region (a.filter_parts parts per region)
  * and compacts it, in order, into an accepted region of its own
- * (region = filter_parts * group + part): no barriers, eight records per lane
- * and iteration.
+ * (region = filter_parts * group + part): no barriers behind the LDS fill.
+ *
+ * An iteration is 512 records, eight consecutive ones per lane (two 16-byte
+ * loads of keys, one 8-byte load of tails), in two stages:
+ *   1  per record, without a branch: kind, address, its bit in the LDS copy of
+ *      the fold -> `maybe`, the lane's records that need a closer look (clean and
+ *      corrected squitters, replies whose fold bit is set: about one record in a
+ *      hundred; everything in SORA_EMIT_CANDIDATES mode)
+ *   2  those records, compacted through a 64-entry queue of the wave in LDS (a
+ *      wave prefix sum of the lanes' counts gives the slots, so the queue is in
+ *      record order), ONE per lane: the record's tile from the region's
+ *      tile_end[] slice, its position, the exact bitmap and first_seen in L2,
+ *      and the kept ones out behind a ballot.
+ * (Until round 3 stage 2 went through the lane's eight records one after the
+ * other under nested branches, with every lane of the wave waiting on the one
+ * or two that had something: 700 instructions per iteration, a third of them
+ * scalar mask bookkeeping; the filter was bound by that, not by its 0.77 GB.)
  */
+/* floor(num / den) for num < 2^53 and den < 2^32, by one division in double: an
+ * integer quotient comes out exactly, and any other lies at least 1 / den from
+ * an integer, further than the division's rounding (num / den * 2^-53) can move
+ * it.  The scan kernel divides the same numbers as integers. */
+__device__ __forceinline__ uint64_t
+exact_quotient(uint64_t num, uint32_t den) {
+    return (uint64_t) ((double) num / (double) den);
+}
+
 constexpr int kFilterWaves = kSmall / 64;
 constexpr int kFilterUnroll = 8;	/* 16 measured: resolve 0.52 -> 0.60 ms */
+constexpr uint32_t kFilterQueue = 64;	/* survivors of stage 1 looked at per round */
 /* a wave's loop is one round trip to HBM per iteration, so the kernel is as fast
  * as there are waves to overlap them: regions are split until there are this
  * many parts (24 waves per CU of a 256-CU part) */
@@ -1294,6 +1319,8 @@ filter_kernel(sora_resolve_args a, uint32_t range_tiles) {
      * known it passes a fraction of a percent of the noise replies, and only
      * those go on to the exact bitmap and the first-seen table in L2 */
     __shared__ uint32_t s_fold[SORA_KNOWN_FOLD_WORDS];
+    /* per wave: key in the low word; tail | index within the iteration << 8 above */
+    __shared__ uint64_t s_queue[kFilterWaves][kFilterQueue];
     /* per wave: the record counts up to the end of each tile of its scan region
      * (sora_scan_args::tile_end); a record's position counts from its tile.
      * Dynamic, as long as the longest range of this scan (`range_tiles`): the
@@ -1304,12 +1331,16 @@ filter_kernel(sora_resolve_args a, uint32_t range_tiles) {
     const bool live = region < a.regions;		/* wave-uniform */
     const uint32_t group = live? region / a.filter_parts : 0;
     const uint32_t part = live? region % a.filter_parts : 0;
-    /* the tiles of the scan region, as the scan kernel computes them */
-    const uint64_t tile_first = a.n_tiles * group / a.groups;
-    uint32_t n_region_tiles = (uint32_t) (a.n_tiles * (group + 1) / a.groups - tile_first);
+    /* the tiles of the scan region, as the scan kernel computes them (quotients
+     * by way of double, see exact_quotient: a 64-bit integer division is a
+     * hundred instructions, and a wave's whole part is a few thousand) */
+    const uint64_t tile_first = exact_quotient(a.n_tiles * group, a.groups);
+    uint32_t n_region_tiles = (uint32_t) (exact_quotient(a.n_tiles * (group + 1), a.groups) -
+	    tile_first);
     if (n_region_tiles > range_tiles)
 	n_region_tiles = range_tiles;			/* not reached: the launcher computes it */
     uint32_t *const te = s_tile_end + wave * range_tiles;
+    uint64_t *const queue = s_queue[wave];
     {
 	const u32x4 *src = reinterpret_cast<const u32x4 *>(a.known_bits +
 		SORA_KNOWN_BITMAP_WORDS);
@@ -1335,19 +1366,14 @@ filter_kernel(sora_resolve_args a, uint32_t range_tiles) {
     /* parts begin at multiples of eight records: with rec_cap a multiple of
      * eight (sora_adsb_scan) a lane's eight keys are 32 aligned bytes and its
      * eight tails 8 */
-    const uint32_t begin = (uint32_t) ((uint64_t) n * part / a.filter_parts) & ~7u;
+    const uint32_t begin = (uint32_t) exact_quotient((uint64_t) n * part, a.filter_parts) & ~7u;
     const uint32_t end = part + 1 == a.filter_parts? n :
-	    (uint32_t) ((uint64_t) n * (part + 1) / a.filter_parts) & ~7u;
+	    (uint32_t) exact_quotient((uint64_t) n * (part + 1), a.filter_parts) & ~7u;
+    const uint32_t all = a.emit_all != 0? 1u : 0u;
 
-    /* a lane takes EIGHT CONSECUTIVE records: two 16-byte loads of keys and an
-     * 8-byte load of tails (three load instructions per 512 records where one
-     * record per lane and load took sixteen); the kept ones go out in lane order
-     * behind a wave prefix sum of the lanes' counts */
     for (uint32_t base = begin; base < end; base += 64 * kFilterUnroll) {
 	const uint32_t i0 = base + lane * kFilterUnroll;
 	uint32_t k[kFilterUnroll], t[kFilterUnroll];
-	uint64_t r[kFilterUnroll];
-	uint32_t keep = 0, maybe = 0, tl, tile_stop;
 	{
 	    u32x4 kq[kFilterUnroll / 4];
 	    uint32_t tq[kFilterUnroll / 4];
@@ -1360,29 +1386,8 @@ filter_kernel(sora_resolve_args a, uint32_t range_tiles) {
 #pragma unroll
 		for (int q = 0; q < kFilterUnroll / 4; q++)
 		    kq[q] = *reinterpret_cast<const u32x4 *>(key + i0 + 4 * q);
-		if constexpr (kFilterUnroll == 16) {
-		    const u32x4 tt = *reinterpret_cast<const u32x4 *>(tail + i0);
-		    tq[0] = tt[0]; tq[1] = tt[1]; tq[2] = tt[2]; tq[3] = tt[3];
-		} else {
-		    const u32x2 tt = *reinterpret_cast<const u32x2 *>(tail + i0);
-		    tq[0] = tt[0]; tq[1] = tt[1];
-		}
-	    }
-	    /* while those are on their way: the tile of the lane's first record,
-	     * from a guess (LDS only; nearly every batch keeps something) */
-	    tl = (uint32_t) ((float) i0 * tiles_per_record);
-	    if (tl >= n_region_tiles)
-		tl = n_region_tiles - 1;
-	    {
-		uint32_t before = tl > 0? te[tl - 1] : 0;
-		tile_stop = te[tl];
-		while (before > i0) {			/* the guess was too far */
-		    tile_stop = before;
-		    tl--;
-		    before = tl > 0? te[tl - 1] : 0;
-		}
-		while (i0 >= tile_stop && tl + 1 < n_region_tiles)
-		    tile_stop = te[++tl];
+		const u32x2 tt = *reinterpret_cast<const u32x2 *>(tail + i0);
+		tq[0] = tt[0]; tq[1] = tt[1];
 	    }
 #pragma unroll
 	    for (int u = 0; u < kFilterUnroll; u++) {
@@ -1390,64 +1395,79 @@ filter_kernel(sora_resolve_args a, uint32_t range_tiles) {
 		t[u] = (tq[u / 4] >> (8 * (u % 4))) & 0xffu;
 	    }
 	}
-	/* first what needs no position: nearly every record is a reply from an
-	 * address nobody has */
+	/* ---- stage 1: which records need a closer look (no branches) ---- */
+	uint32_t maybe = 0;
 #pragma unroll
 	for (int u = 0; u < kFilterUnroll; u++) {
 	    const uint32_t kind = (k[u] >> 24) & 3u;
 	    const uint32_t addr = k[u] & 0xffffffu;
-	    bool open = false;
-	    if (i0 + u >= end) {
-		/* past the part: dropped */
-	    } else if (kind == SORA_REC_KIND_SQUITTER || kind == SORA_REC_KIND_CORRECTED) {
-		open = true;
-	    } else if (kind == SORA_REC_KIND_REPLY) {
-		const uint32_t f = addr & ((1u << SORA_KNOWN_FOLD_BITS) - 1);
-		bool known = (s_fold[f >> 5] >> (addr & 31)) & 1;
-		if (known)
-		    known = (a.known_bits[addr >> 5] >> (addr & 31)) & 1;
-		open = known || a.emit_all;
-	    } else {				/* SORA_REC_KIND_DIRTY */
-		open = a.emit_all != 0;
-	    }
-	    maybe |= (uint32_t) open << u;
+	    /* a squitter's payload is its list index, not an address: its lookup is
+	     * idle work, cheaper than a branch around it */
+	    const uint32_t bit = (s_fold[(addr & ((1u << SORA_KNOWN_FOLD_BITS) - 1)) >> 5] >>
+		    (addr & 31)) & 1u;
+	    /* kind: 0 reply, 1 squitter, 2 dirty, 3 corrected */
+	    uint32_t open = (kind & 1u) | all | ((kind == SORA_REC_KIND_REPLY? 1u : 0u) & bit);
+	    open &= i0 + u < end? 1u : 0u;
+	    maybe |= open << u;
 	}
-	/* then the position of those -- on from the tile of the lane's first
-	 * record -- and the rule that needs it */
-	if (maybe != 0) {
+	const uint32_t cnt = __popc(maybe);
+	if (__ballot(cnt != 0) == 0)
+	    continue;				/* wave-uniform */
+	/* ---- stage 2: those records, one per lane, in record order ---- */
+	const uint32_t incl = wave_inclusive_scan(cnt);
+	const uint32_t total = (uint32_t) __builtin_amdgcn_readlane((int) incl, 63);
+	for (uint32_t round = 0; round < total; round += kFilterQueue) {
+	    {
+		uint32_t slot = incl - cnt - round;	/* wraps below the round's window */
 #pragma unroll
-	    for (int u = 0; u < kFilterUnroll; u++) {
-		while (i0 + u >= tile_stop && tl + 1 < n_region_tiles)
-		    tile_stop = te[++tl];
-		if (maybe & (1u << u)) {
-		    const uint32_t kind = (k[u] >> 24) & 3u;
-		    const uint32_t addr = k[u] & 0xffffffu;
-		    const uint64_t pos = (tile_first + tl) * a.tile_pos + (((k[u] >> 26) << 8) | t[u]);
-		    bool accepted = kind != SORA_REC_KIND_REPLY && kind != SORA_REC_KIND_DIRTY;
-		    if (kind == SORA_REC_KIND_REPLY)	/* its address is known: since when? */
-			accepted = ((a.known_bits[addr >> 5] >> (addr & 31)) & 1) &&
-				(kHashed? seen_lookup_hashed(a, addr) : a.first_seen[addr]) <
-				(a.seen_tag | (a.base_position + pos));
-		    r[u] = sora_rec_make(kind, pos, addr);
-		    if (accepted)
-			r[u] |= SORA_REC_ACCEPTED << 60;
-		    if (accepted || a.emit_all)
-			keep |= 1u << u;
-		}
+		for (int u = 0; u < kFilterUnroll; u++)
+		    if (maybe & (1u << u)) {
+			if (slot < kFilterQueue)
+			    queue[slot] = (uint64_t) k[u] |
+				    ((uint64_t) (t[u] | ((lane * kFilterUnroll + u) << 8)) << 32);
+			slot++;
+		    }
 	    }
-	}
-	if (__ballot(keep != 0) != 0) {		/* most batches of noise keep nothing */
-	    const uint32_t cnt = __popc(keep);
-	    const uint32_t incl = wave_inclusive_scan(cnt);
-	    uint32_t idx = n_acc + incl - cnt;
-#pragma unroll
-	    for (int u = 0; u < kFilterUnroll; u++)
-		if (keep & (1u << u)) {
-		    if (idx < a.acc_cap)
-			acc[idx] = r[u];
-		    idx++;
-		}
-	    n_acc += (uint32_t) __builtin_amdgcn_readlane((int) incl, 63);
+	    /* the queue is this wave's alone and a wave's LDS operations complete
+	     * in order: no barrier, only no reordering by the compiler */
+	    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	    __builtin_amdgcn_wave_barrier();
+	    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+	    const uint32_t here = total - round < kFilterQueue? total - round : kFilterQueue;
+	    bool keep = false;
+	    uint64_t rec = 0;
+	    if (lane < here) {
+		const uint64_t e = queue[lane];
+		const uint32_t kk = (uint32_t) e, hi = (uint32_t) (e >> 32);
+		const uint32_t i = base + (hi >> 8);		/* the record's slot in the region */
+		const uint32_t kind = (kk >> 24) & 3u, addr = kk & 0xffffffu;
+		/* its tile: from a proportional guess, then along tile_end[] */
+		uint32_t tl = (uint32_t) ((float) i * tiles_per_record);
+		if (tl >= n_region_tiles)
+		    tl = n_region_tiles - 1;
+		while (tl > 0 && te[tl - 1] > i)
+		    tl--;
+		while (tl + 1 < n_region_tiles && te[tl] <= i)
+		    tl++;
+		const uint64_t pos = (tile_first + tl) * a.tile_pos + (((kk >> 26) << 8) | (hi & 0xffu));
+		bool accepted = (kind & 1u) != 0;		/* clean or corrected squitter */
+		if (kind == SORA_REC_KIND_REPLY)		/* is its address known, and since when? */
+		    accepted = ((a.known_bits[addr >> 5] >> (addr & 31)) & 1) &&
+			    (kHashed? seen_lookup_hashed(a, addr) : a.first_seen[addr]) <
+			    (a.seen_tag | (a.base_position + pos));
+		rec = sora_rec_make(kind, pos, addr);
+		if (accepted)
+		    rec |= SORA_REC_ACCEPTED << 60;
+		keep = accepted || all != 0;
+	    }
+	    const unsigned long long kept = __ballot(keep);
+	    if (keep) {
+		const uint32_t idx = n_acc + rank_in_mask(kept);
+		if (idx < a.acc_cap)
+		    acc[idx] = rec;
+	    }
+	    n_acc += (uint32_t) __popcll(kept);
+	    __builtin_amdgcn_wave_barrier();	/* the next round refills the queue */
 	}
     }
     if (lane == 0) {
