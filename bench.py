@@ -78,6 +78,13 @@ def parse_args():
     ap.add_argument("--overlap", action="store_true",
                     help="experiment: do not order the kernels of different captures "
                          "by events (a scan may share the GPU with a resolve)")
+    ap.add_argument("--archive", type=int, default=0, metavar="R",
+                    help="side mode, BASELINE.json configs[4]: R independent recordings per "
+                         "GPU (120 M samples each by default, --archive-samples; uc8 and sc8 "
+                         "alternating, a seed each) through one pair of contexts with "
+                         "sora_adsb_reset() between them; a step is one pass over the R "
+                         "recordings.  Replicas only: no collective at any N")
+    ap.add_argument("--archive-samples", type=float, default=120e6)
     ap.add_argument("--force-collective", action="store_true",
                     help="run the N>1 exchange code path even with one rank (rehearsal)")
     return ap.parse_args()
@@ -170,6 +177,127 @@ def cpu_baseline(d_iq, n_cpu, gpu_accepted_in_window):
     }
 
 
+def run_archive(args, json_fd):
+    """configs[4]: archive reprocessing.  64 recordings over 8 GPUs are 8 per GPU;
+    every rank works through its own R recordings (independent plane sets:
+    sora_adsb_reset() between recordings, one capture = one recording) with two
+    contexts in flight.  No data-path collective: replicas only."""
+    import torch
+    import torch.distributed as dist
+
+    import sora_amd
+    from sora_amd import AdsbContext, synth
+    from sora_amd._lib import ENC_SC8, ENC_UC8
+    from sora_amd.sharded import LocalDecoder
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    n, R = int(args.archive_samples), args.archive
+    recs = []
+    for i in range(R):
+        enc = ENC_UC8 if i % 2 == 0 else ENC_SC8
+        p = synth.default_params(5, n_samples=n, seed=0x5eed0000 + 97 * (rank * R + i))
+        p.encoding = enc
+        frames = synth.make_frames(p)
+        d = torch.empty(2 * n + 16, dtype=torch.uint8, device=dev)
+        synth.fill_device(d.data_ptr(), n, enc, p.seed, frames)
+        recs.append((d, enc, len(frames)))
+    torch.cuda.synchronize()
+    max_frames = n // 1024 + 65536
+    scan_stream = torch.cuda.Stream(device=dev, priority=0)
+    ctxs, decs = [], []
+    for _ in range(2):
+        rs = torch.cuda.Stream(device=dev, priority=args.resolve_priority)
+        ctx = AdsbContext(n, device=local, max_squitters=max_frames, max_frames=max_frames,
+                          stream=scan_stream.cuda_stream, wire_frames=args.frames == "wire",
+                          resolve_stream=rs.cuda_stream)
+        ctxs.append(ctx)
+        decs.append(LocalDecoder(ctx, max_frames))
+    scan_ms, counts = [], [0] * R
+
+    def one_pass():
+        prev = None
+        for i, (d, enc, _) in enumerate(recs):
+            dec = decs[i % 2]
+            dec.begin(d, 2 * n, enc, 0, n)          # reset: a new recording
+            dec.exchange()
+            if prev is not None:
+                counts[prev[0]] = prev[1].finish()
+                scan_ms.append(prev[1].ctx.last_scan_ms())
+            prev = (i, dec)
+        counts[prev[0]] = prev[1].finish()
+        scan_ms.append(prev[1].ctx.last_scan_ms())
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_pass()
+    fence()
+    scan_ms.clear()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_pass()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    kernel_ms = float(np.mean(scan_ms))
+    ms_per_step = dt / args.steps * 1e3
+    total = world * R * n
+    line = {
+        "metric": "Msamples/s ADS-B decoded (2MS/s uc8+sc8 IQ, archive)",
+        "value": round(total * args.steps / dt / 1e6, 1), "unit": "Msamples/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {
+            "workload": (f"side measurement, configs[4]: archive reprocessing, {R} independent "
+                         f"recordings of {n} samples per GPU (uc8 and sc8 alternating, a seed "
+                         "each), sora_adsb_reset() + scan + resolve + frame list to host per "
+                         "recording; a step is one pass over the recordings of a GPU"),
+            "parallelism": "replicas only: every rank its own recordings, no collective",
+            "recordings_per_gpu": R, "samples_per_recording": n,
+            "frames_out_rank0": [int(c) for c in counts],
+            "injected_frames_rank0": [int(r[2]) for r in recs],
+            "list_regrows_rank0": [int(c.list_regrows()) for c in ctxs],
+            "ms_per_recording": round(ms_per_step / R, 4),
+        },
+        "roofline": {
+            "bound": "hbm", "achieved": round(2 * n / (kernel_ms * 1e-3) / 1e9, 1),
+            "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(2 * n / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+            "step_frac": round(2 * n * R / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "kernel": "adsb_scan_direct_kernel<256> (uc8, sc8)", "kernel_ms": round(kernel_ms, 4),
+            "algorithmic_bytes": 2 * n,
+        },
+        "cpu_baseline": None,
+    }
+    if rank == 0 and not args.no_cpu and args.cpu_samples > 0:
+        # recording 0 (uc8) whole through the compiled reference: the same frames?
+        d, enc, _ = recs[0]
+        line["cpu_baseline"] = cpu_baseline(d, n, counts[0])
+    if rank == 0:
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
+    for c in ctxs:
+        c.close()
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
 def main():
     args = parse_args()
     # stdout carries the one JSON line and nothing else: libraries that print
@@ -177,6 +305,8 @@ def main():
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
+    if args.archive > 0:
+        return run_archive(args, json_fd)
     import torch
     import torch.distributed as dist
 
@@ -357,6 +487,18 @@ def main():
     counts = ctx.counts()
     kernel_name = ctx.scan_kernel_name(enc)      # the kernel this context launched
     kernel_ms = float(np.mean(scan_ms))
+    # With two streams a scan shares the GPU with the previous capture's resolve,
+    # and its launch lasts longer for it: the roofline figure below is that
+    # duration, as the timed region had it.  Beside it, behind the timed region,
+    # the same launch with the GPU to itself (scans back to back, nothing else queued).
+    alone = []
+    for _ in range(3):
+        for _ in range(8):      # back to back (the clock sags behind an idle GPU);
+            ctx.reset()         # the events hold the last launch
+            ctx.scan(*job[:3], base_position=first, n_owned=per_gpu)
+        ctx.synchronize()
+        alone.append(ctx.last_scan_ms())
+    kernel_ms_alone = float(np.mean(alone))
     # HBM bytes per launch from the PMC passes of this same workload
     # (tools/hbm_traffic.py: FETCH_SIZE x2 + WRITE_SIZE); null if none matches
     traffic = traffic_source = None
@@ -390,6 +532,13 @@ def main():
     else:
         workload = (f"side measurement: {total} samples of {args.encoding} over {world} "
                     "GPU(s), scan + resolve + frame list to host")
+    # what "frame list to host" is in this run (the advisor's note on round 2: the
+    # 28-byte form is a different deliverable from the 48-byte struct and the line
+    # must say which one it timed)
+    workload += (" (28-byte wire frames, SORA_OPT_WIRE_FRAMES: bits, position, amplitude, "
+                 "flags; DF / syndrome / address are derived from the bits on demand by "
+                 "sora_adsb_unpack_frames, outside the step)" if args.frames == "wire" else
+                 " (48-byte struct sora_adsb_frame)")
     line = {
         "metric": f"Msamples/s ADS-B decoded (2MS/s {args.encoding} IQ)",
         "value": round(total * args.steps / dt / 1e6, 1),
@@ -429,6 +578,12 @@ def main():
                             "step (scan + resolve + frames to host), not the scan kernel alone",
             "kernel": f"{kernel_name} ({args.encoding})",
             "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes": n_local * bps,
+            "kernel_ms_unshared": round(kernel_ms_alone, 4),
+            "frac_unshared": round(n_local * bps / (kernel_ms_alone * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "unshared_is": "the same launch with the GPU to itself (behind the timed region); "
+                           "`achieved` / `frac` are the launches of the timed region, which "
+                           + ("share the GPU with the previous capture's resolve" if two_stream
+                              else "run alone as well (events schedule)"),
         },
     }
 
