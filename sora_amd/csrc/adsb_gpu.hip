@@ -247,7 +247,7 @@ bind_lists(sora_adsb_ctx *ctx) {
     a.tile_end = ctx->d_tile_end;
     a.sq = ctx->d_sq;
     a.sq_bits = ctx->d_sq_bits;
-    a.rec_cap = share(ctx->rec_total, groups) & ~7u;	/* >= 8: sora_adsb_scan */
+    a.rec_cap = share(ctx->rec_total, groups) & ~15u;	/* >= 16: sora_adsb_scan */
     a.sq_cap = share(ctx->sq_total, groups);
     r.key = a.key;
     r.tail = a.tail;
@@ -473,7 +473,7 @@ sora_adsb_create(sora_adsb_ctx **out, int device, const sora_adsb_config *cfg) {
 
     const uint64_t n = cfg->max_chunk_samples;
     ctx->rec_total = cfg->max_candidates != 0? cfg->max_candidates : n / 16 + 65536;
-    ctx->rec_total = (ctx->rec_total + 7) & ~7ull;	/* regions of whole 8-record groups */
+    ctx->rec_total = (ctx->rec_total + 15) & ~15ull;	/* regions of whole 16-record groups */
     ctx->sq_total = cfg->max_squitters != 0? cfg->max_squitters : n / 256 + 65536;
     ctx->acc_total = cfg->max_frames != 0? cfg->max_frames :
 	    cfg->emit_mode == SORA_EMIT_CANDIDATES? ctx->rec_total : ctx->sq_total;
@@ -549,10 +549,11 @@ sora_adsb_scan(sora_adsb_ctx *ctx, const void *d_iq, size_t nbytes, int encoding
 	return fail(ctx, SORA_ERR_INVALID, "%llu tiles for %llu slots", (unsigned long long) n_tiles,
 		(unsigned long long) ctx->tile_slots);
 
-    /* the filter loads eight records at a time, aligned: a region holds at
-     * least eight (few, long regions when the record list is tiny) */
-    if (ctx->rec_total / groups < 8)
-	groups = ctx->rec_total / 8 > 0? (uint32_t) (ctx->rec_total / 8) : 1;
+    /* the filter loads a lane's records (eight; sixteen in an experiment build)
+     * with aligned 16-byte loads: a region is whole groups of sixteen and holds at
+     * least one (few, long regions when the record list is tiny) */
+    if (ctx->rec_total / groups < 16)
+	groups = ctx->rec_total / 16 > 0? (uint32_t) (ctx->rec_total / 16) : 1;
 
     /* the tiles of a workgroup's range have a word each in the LDS of the scan
      * kernel and of the filter: SORA_RANGE_TILES_MAX (adsb_kernels.h) */
@@ -882,7 +883,7 @@ ensure_complete(sora_adsb_ctx *ctx, bool *overflow) {
 
 	/* a quarter more than was needed, shared out evenly like the lists are */
 	const auto grown = [](uint64_t per_region, uint32_t regions) {
-	    return ((per_region + per_region / 4 + 15) & ~7ull) * regions;
+	    return ((per_region + per_region / 4 + 31) & ~15ull) * regions;
 	};
 	uint64_t rec_total = ctx->rec_total, sq_total = ctx->sq_total;
 	uint64_t acc_total = ctx->acc_total, frames_cap = ctx->frames_cap;

@@ -1305,7 +1305,12 @@ exact_quotient(uint64_t num, uint32_t den) {
 }
 
 constexpr int kFilterWaves = kSmall / 64;
-constexpr int kFilterUnroll = 8;	/* 16 measured: resolve 0.52 -> 0.60 ms */
+#ifndef SORA_FILTER_UNROLL
+#define SORA_FILTER_UNROLL 8
+#endif
+constexpr int kFilterUnroll = SORA_FILTER_UNROLL;	/* records per lane and iteration (16, and
+							 * the next iteration's loads issued ahead:
+							 * both measured, no change) */
 constexpr uint32_t kFilterQueue = 64;	/* survivors of stage 1 looked at per round */
 /* a wave's loop is one round trip to HBM per iteration, so the kernel is as fast
  * as there are waves to overlap them: regions are split until there are this
@@ -1366,9 +1371,10 @@ filter_kernel(sora_resolve_args a, uint32_t range_tiles) {
     /* parts begin at multiples of eight records: with rec_cap a multiple of
      * eight (sora_adsb_scan) a lane's eight keys are 32 aligned bytes and its
      * eight tails 8 */
-    const uint32_t begin = (uint32_t) exact_quotient((uint64_t) n * part, a.filter_parts) & ~7u;
+    constexpr uint32_t kAlign = ~(uint32_t) (kFilterUnroll - 1);
+    const uint32_t begin = (uint32_t) exact_quotient((uint64_t) n * part, a.filter_parts) & kAlign;
     const uint32_t end = part + 1 == a.filter_parts? n :
-	    (uint32_t) exact_quotient((uint64_t) n * (part + 1), a.filter_parts) & ~7u;
+	    (uint32_t) exact_quotient((uint64_t) n * (part + 1), a.filter_parts) & kAlign;
     const uint32_t all = a.emit_all != 0? 1u : 0u;
 
     for (uint32_t base = begin; base < end; base += 64 * kFilterUnroll) {
@@ -1386,13 +1392,18 @@ filter_kernel(sora_resolve_args a, uint32_t range_tiles) {
 #pragma unroll
 		for (int q = 0; q < kFilterUnroll / 4; q++)
 		    kq[q] = *reinterpret_cast<const u32x4 *>(key + i0 + 4 * q);
-		const u32x2 tt = *reinterpret_cast<const u32x2 *>(tail + i0);
-		tq[0] = tt[0]; tq[1] = tt[1];
+		if constexpr (kFilterUnroll == 16) {
+		    const u32x4 tt = *reinterpret_cast<const u32x4 *>(tail + i0);
+		    tq[0] = tt[0]; tq[1] = tt[1]; tq[2] = tt[2]; tq[3] = tt[3];
+		} else {
+		    const u32x2 tt = *reinterpret_cast<const u32x2 *>(tail + i0);
+		    tq[0] = tt[0]; tq[1] = tt[1];
+		}
 	    }
 #pragma unroll
 	    for (int u = 0; u < kFilterUnroll; u++) {
 		k[u] = kq[u / 4][u % 4];
-		t[u] = (tq[u / 4] >> (8 * (u % 4))) & 0xffu;
+		t[u] = tq[u / 4];	/* the tail is byte u % 4 of it: cut out for survivors only */
 	    }
 	}
 	/* ---- stage 1: which records need a closer look (no branches) ---- */
@@ -1406,9 +1417,15 @@ filter_kernel(sora_resolve_args a, uint32_t range_tiles) {
 	    const uint32_t bit = (s_fold[(addr & ((1u << SORA_KNOWN_FOLD_BITS) - 1)) >> 5] >>
 		    (addr & 31)) & 1u;
 	    /* kind: 0 reply, 1 squitter, 2 dirty, 3 corrected */
-	    uint32_t open = (kind & 1u) | all | ((kind == SORA_REC_KIND_REPLY? 1u : 0u) & bit);
-	    open &= i0 + u < end? 1u : 0u;
+	    const uint32_t open = (kind == SORA_REC_KIND_REPLY? bit : kind) & 1u;
 	    maybe |= open << u;
+	}
+	{
+	    /* the records of this lane that exist; everything in emit-all mode */
+	    constexpr uint32_t kAll = (1u << kFilterUnroll) - 1u;
+	    const uint32_t left = i0 < end? end - i0 : 0u;
+	    const uint32_t valid = left >= (uint32_t) kFilterUnroll? kAll : (1u << left) - 1u;
+	    maybe = (all != 0? kAll : maybe) & valid;
 	}
 	const uint32_t cnt = __popc(maybe);
 	if (__ballot(cnt != 0) == 0)
@@ -1424,7 +1441,8 @@ filter_kernel(sora_resolve_args a, uint32_t range_tiles) {
 		    if (maybe & (1u << u)) {
 			if (slot < kFilterQueue)
 			    queue[slot] = (uint64_t) k[u] |
-				    ((uint64_t) (t[u] | ((lane * kFilterUnroll + u) << 8)) << 32);
+				    ((uint64_t) (((t[u] >> (8 * (u % 4))) & 0xffu) |
+				    ((lane * kFilterUnroll + u) << 8)) << 32);
 			slot++;
 		    }
 	    }

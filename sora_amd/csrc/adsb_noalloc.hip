@@ -54,7 +54,7 @@ constexpr uint64_t kOffTileEnd = kOffStats + aligned((uint64_t) kMaxGroups * SOR
 constexpr uint64_t kTileSlots = kMaxSamples / 7808 + 16;	/* no scan kernel's tile is shorter */
 constexpr uint64_t kScratchUsed = kOffTileEnd + aligned(kTileSlots * 4);
 static_assert(kScratchUsed <= SORA_NOALLOC_SCRATCH_BYTES, "the lists do not fit the array");
-static_assert((kRecSlots & 7) == 0, "record regions are whole 8-record groups");
+static_assert((kRecSlots & 15) == 0, "record regions are whole 16-record groups");
 
 } /* namespace */
 
@@ -170,7 +170,7 @@ sora_adsb_decode_noalloc(int device, void *stream_, const void *d_iq, size_t nby
      * slots suffice (one region always does) */
     const auto region_slots = [&](uint32_t g) {
 	const uint64_t tiles = (n_tiles + g - 1) / g;
-	return (uint32_t) ((tiles * tile_pos / 2 + 8 + 7) & ~7ull);
+	return (uint32_t) ((tiles * tile_pos / 2 + 8 + 15) & ~15ull);
     };
     while (groups > 1 && (uint64_t) groups * region_slots(groups) > kRecSlots)
 	groups--;
