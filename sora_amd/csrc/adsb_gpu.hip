@@ -240,17 +240,14 @@ bind_lists(sora_adsb_ctx *ctx) {
 	return (uint32_t) (each > 0x7fffffffull? 0x7fffffffull : each);
     };
 
-    /* the record buffer holds the 4-byte keys, then the 1-byte tails */
-    a.key = reinterpret_cast<uint32_t *>(ctx->d_rec);
-    a.tail = reinterpret_cast<uint8_t *>(reinterpret_cast<uint32_t *>(ctx->d_rec) +
-	    ctx->rec_total);			/* rec_total is a multiple of 8 */
+    /* the record buffer: units of SORA_REC_UNIT records, keys then tails */
+    a.rec = reinterpret_cast<uint8_t *>(ctx->d_rec);
     a.tile_end = ctx->d_tile_end;
     a.sq = ctx->d_sq;
     a.sq_bits = ctx->d_sq_bits;
-    a.rec_cap = share(ctx->rec_total, groups) & ~15u;	/* >= 16: sora_adsb_scan */
+    a.rec_cap = share(ctx->rec_total, groups) & ~(SORA_REC_UNIT - 1);	/* >= a unit: sora_adsb_scan */
     a.sq_cap = share(ctx->sq_total, groups);
-    r.key = a.key;
-    r.tail = a.tail;
+    r.rec = a.rec;
     r.tile_end = a.tile_end;
     r.rec_cap = a.rec_cap;
     r.sq = ctx->d_sq;
@@ -473,7 +470,7 @@ sora_adsb_create(sora_adsb_ctx **out, int device, const sora_adsb_config *cfg) {
 
     const uint64_t n = cfg->max_chunk_samples;
     ctx->rec_total = cfg->max_candidates != 0? cfg->max_candidates : n / 16 + 65536;
-    ctx->rec_total = (ctx->rec_total + 15) & ~15ull;	/* regions of whole 16-record groups */
+    ctx->rec_total = (ctx->rec_total + SORA_REC_UNIT - 1) & ~(uint64_t) (SORA_REC_UNIT - 1);	/* whole units */
     ctx->sq_total = cfg->max_squitters != 0? cfg->max_squitters : n / 256 + 65536;
     ctx->acc_total = cfg->max_frames != 0? cfg->max_frames :
 	    cfg->emit_mode == SORA_EMIT_CANDIDATES? ctx->rec_total : ctx->sq_total;
@@ -549,11 +546,10 @@ sora_adsb_scan(sora_adsb_ctx *ctx, const void *d_iq, size_t nbytes, int encoding
 	return fail(ctx, SORA_ERR_INVALID, "%llu tiles for %llu slots", (unsigned long long) n_tiles,
 		(unsigned long long) ctx->tile_slots);
 
-    /* the filter loads a lane's records (eight; sixteen in an experiment build)
-     * with aligned 16-byte loads: a region is whole groups of sixteen and holds at
-     * least one (few, long regions when the record list is tiny) */
-    if (ctx->rec_total / groups < 16)
-	groups = ctx->rec_total / 16 > 0? (uint32_t) (ctx->rec_total / 16) : 1;
+    /* a region is whole units of SORA_REC_UNIT records (sora_scan_args::rec) and
+     * holds at least one (few, long regions when the record list is tiny) */
+    if (ctx->rec_total / groups < SORA_REC_UNIT)
+	groups = ctx->rec_total / SORA_REC_UNIT > 0? (uint32_t) (ctx->rec_total / SORA_REC_UNIT) : 1;
 
     /* the tiles of a workgroup's range have a word each in the LDS of the scan
      * kernel and of the filter: SORA_RANGE_TILES_MAX (adsb_kernels.h) */
@@ -883,7 +879,7 @@ ensure_complete(sora_adsb_ctx *ctx, bool *overflow) {
 
 	/* a quarter more than was needed, shared out evenly like the lists are */
 	const auto grown = [](uint64_t per_region, uint32_t regions) {
-	    return ((per_region + per_region / 4 + 31) & ~15ull) * regions;
+	    return ((per_region + per_region / 4 + 2 * SORA_REC_UNIT - 1) & ~(uint64_t) (SORA_REC_UNIT - 1)) * regions;
 	};
 	uint64_t rec_total = ctx->rec_total, sq_total = ctx->sq_total;
 	uint64_t acc_total = ctx->acc_total, frames_cap = ctx->frames_cap;

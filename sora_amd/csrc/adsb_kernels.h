@@ -44,8 +44,13 @@ struct sora_scan_args {
      * counts from the first position of the candidate's tile (< 2^14 in every
      * scan kernel).  Which tile: tile_end[t], for every tile t of the chunk, is
      * the number of records of t's workgroup range up to and including t */
-    uint32_t *key;		/* [groups][rec_cap] */
-    uint8_t *tail;		/* [groups][rec_cap] */
+    /* Both in ONE array, in units of SORA_REC_UNIT records: the unit's keys
+     * (4 bytes each), then its tails -- 5 * SORA_REC_UNIT bytes per unit, a region
+     * is rec_cap / SORA_REC_UNIT units (rec_cap is a multiple of the unit).  A
+     * flush of the scan kernel (1024 records) is then one contiguous 5 KB piece,
+     * and a filter iteration reads its keys and tails out of the same piece
+     * (until round 3 two arrays: two thin store streams beside the reads). */
+    uint8_t *rec;		/* [groups][rec_cap / SORA_REC_UNIT] units */
     uint32_t *tile_end;		/* [n_tiles] */
     uint64_t *sq;		/* [groups][sq_cap] clean squitters */
     /* [groups][sq_cap][4]: the 112 message bits of each of them as phase 4
@@ -78,8 +83,7 @@ struct sora_resolve_args {
     int32_t encoding;
     int32_t emit_all;
     uint32_t groups;
-    const uint32_t *key;	/* scan output, see sora_scan_args */
-    const uint8_t *tail;
+    const uint8_t *rec;		/* scan output, see sora_scan_args */
     const uint32_t *tile_end;
     uint64_t n_tiles;		/* of the scan: region g starts at tile n_tiles * g / groups */
     uint32_t tile_pos;		/* positions per tile of the scan kernel that ran */
@@ -126,6 +130,15 @@ struct sora_resolve_args {
 };
 
 #define SORA_SEEN_EMPTY		0xffffffffu
+
+/* candidate records in memory (sora_scan_args::rec) */
+#define SORA_REC_UNIT		256u			/* records per unit */
+#define SORA_REC_UNIT_BYTES	(5u * SORA_REC_UNIT)	/* keys, then tails */
+/* byte offset, from the start of a region, of record i's key and of its tail */
+#define SORA_REC_KEY_AT(i)	(((i) / SORA_REC_UNIT) * SORA_REC_UNIT_BYTES + 4u * ((i) % SORA_REC_UNIT))
+#define SORA_REC_TAIL_AT(i)	(((i) / SORA_REC_UNIT) * SORA_REC_UNIT_BYTES + 4u * SORA_REC_UNIT + (i) % SORA_REC_UNIT)
+/* bytes of a region of rec_cap records */
+#define SORA_REC_REGION_BYTES(rec_cap)	((uint64_t) ((rec_cap) / SORA_REC_UNIT) * SORA_REC_UNIT_BYTES)
 
 #define SORA_SUM_REC_OVER	0	/* max records of a scan region beyond rec_cap */
 #define SORA_SUM_SQ_OVER	1	/* ... squitters beyond sq_cap */

@@ -261,8 +261,7 @@ adsb_scan_kernel(sora_scan_args a) {
     const uint64_t tile_begin = a.n_tiles * group / groups;
     const uint64_t tile_end = a.n_tiles * (group + 1) / groups;
 
-    uint32_t *key_out = a.key + (uint64_t) group * a.rec_cap;
-    uint8_t *tail_out = a.tail + (uint64_t) group * a.rec_cap;
+    uint8_t *rec_out = a.rec + group * SORA_REC_REGION_BYTES(a.rec_cap);
     uint64_t *sq_out = a.sq + (uint64_t) group * a.sq_cap;
     u32x4 *sq_bits_out = reinterpret_cast<u32x4 *>(a.sq_bits) + (uint64_t) group * a.sq_cap;
     uint32_t n_rec = 0;			/* workgroup-uniform */
@@ -506,8 +505,9 @@ adsb_scan_kernel(sora_scan_args a) {
 		/* key and tail (sora_scan_args) */
 		const uint32_t idx = n_rec + i;
 		if (idx < a.rec_cap) {
-		    key_out[idx] = word | ((uint32_t) kind << 24) | ((q >> 8) << 26);
-		    tail_out[idx] = (uint8_t) q;
+		    *reinterpret_cast<uint32_t *>(rec_out + SORA_REC_KEY_AT(idx)) =
+			    word | ((uint32_t) kind << 24) | ((q >> 8) << 26);
+		    rec_out[SORA_REC_TAIL_AT(idx)] = (uint8_t) q;
 		}
 		/* wave-uniform counts: ballots land in SGPRs, off the VALU */
 		st_sq += (uint32_t) __popcll(__ballot(kind == SORA_REC_KIND_SQUITTER));
@@ -668,11 +668,10 @@ adsb_scan_direct_kernel(sora_scan_args a) {
     /* The record region of this workgroup as two buffers: a store beyond the
      * region (a full region, or a lane that has no record: offset ~0) is
      * dropped by the bounds check -- no branch around the stores. */
-    const uint64_t rec_bytes = (uint64_t) a.rec_cap * 4;
-    auto rsrc_key = __builtin_amdgcn_make_buffer_rsrc(a.key + (uint64_t) group * a.rec_cap, 0,
+    const uint64_t rec_bytes = SORA_REC_REGION_BYTES(a.rec_cap);
+    uint8_t *const rec_out = a.rec + group * rec_bytes;
+    auto rsrc_rec = __builtin_amdgcn_make_buffer_rsrc(rec_out, 0,
 	    rec_bytes > 0xfffffffcull? 0xfffffffcu : (uint32_t) rec_bytes, 0x00020000);
-    auto rsrc_tail = __builtin_amdgcn_make_buffer_rsrc(a.tail + (uint64_t) group * a.rec_cap, 0,
-	    a.rec_cap, 0x00020000);
 
     {
 	const u32x4 *src = reinterpret_cast<const u32x4 *>(g_crc_slices.w);
@@ -722,8 +721,12 @@ adsb_scan_direct_kernel(sora_scan_args a) {
 	    k4 = *reinterpret_cast<const u32x4 *>(&s_stage_key[first & (kStageRing - 1)]);
 	    t4 = *reinterpret_cast<const uint32_t *>(&s_stage_tail[first & (kStageRing - 1)]);
 	}
-	__builtin_amdgcn_raw_buffer_store_b128(k4, rsrc_key, live? first * 4 : 0xffffffffu, 0, 0);
-	__builtin_amdgcn_raw_buffer_store_b32(t4, rsrc_tail, live? first : 0xffffffffu, 0, 0);
+	/* four records of one unit (the unit is a multiple of four): their keys
+	 * and their tails lie in the same 1280-byte unit, a flush is one piece */
+	__builtin_amdgcn_raw_buffer_store_b128(k4, rsrc_rec,
+		live? SORA_REC_KEY_AT(first) : 0xffffffffu, 0, 0);
+	__builtin_amdgcn_raw_buffer_store_b32(t4, rsrc_rec,
+		live? SORA_REC_TAIL_AT(first) : 0xffffffffu, 0, 0);
     };
 
     /*
@@ -958,12 +961,12 @@ adsb_scan_direct_kernel(sora_scan_args a) {
     lds_barrier();			/* the last tile's records and squitter appends */
     {
 	/* what is left in the ring: fewer than kStageUnit + kStagePass records */
-	uint32_t *key_out = a.key + (uint64_t) group * a.rec_cap;
-	uint8_t *tail_out = a.tail + (uint64_t) group * a.rec_cap;
+
 	const uint32_t end = n_rec < a.rec_cap? n_rec : a.rec_cap;
 	for (uint32_t i = n_flushed + tid; i < end; i += kThreads) {
-	    key_out[i] = s_stage_key[i & (kStageRing - 1)];
-	    tail_out[i] = s_stage_tail[i & (kStageRing - 1)];
+	    *reinterpret_cast<uint32_t *>(rec_out + SORA_REC_KEY_AT(i)) =
+		    s_stage_key[i & (kStageRing - 1)];
+	    rec_out[SORA_REC_TAIL_AT(i)] = s_stage_tail[i & (kStageRing - 1)];
 	}
 	const uint64_t mine = tile_end - tile_begin;
 	for (uint64_t i = tid; i < mine && i < (uint64_t) SORA_RANGE_TILES_MAX; i += kThreads)
@@ -1358,8 +1361,7 @@ filter_kernel(sora_resolve_args a, uint32_t range_tiles) {
     __syncthreads();
     if (!live)				/* no barrier below */
 	return;
-    const uint32_t *key = a.key + (uint64_t) group * a.rec_cap;
-    const uint8_t *tail = a.tail + (uint64_t) group * a.rec_cap;
+    const uint8_t *rec = a.rec + group * SORA_REC_REGION_BYTES(a.rec_cap);
     uint64_t *acc = a.acc + (uint64_t) region * a.acc_cap;
     uint32_t n = a.rec_count[group];
     uint32_t n_acc = 0;
@@ -1391,12 +1393,12 @@ filter_kernel(sora_resolve_args a, uint32_t range_tiles) {
 	    if (i0 < end) {		/* the loads may pass `end`, never the list */
 #pragma unroll
 		for (int q = 0; q < kFilterUnroll / 4; q++)
-		    kq[q] = *reinterpret_cast<const u32x4 *>(key + i0 + 4 * q);
+		    kq[q] = *reinterpret_cast<const u32x4 *>(rec + SORA_REC_KEY_AT(i0) + 16 * q);
 		if constexpr (kFilterUnroll == 16) {
-		    const u32x4 tt = *reinterpret_cast<const u32x4 *>(tail + i0);
+		    const u32x4 tt = *reinterpret_cast<const u32x4 *>(rec + SORA_REC_TAIL_AT(i0));
 		    tq[0] = tt[0]; tq[1] = tt[1]; tq[2] = tt[2]; tq[3] = tt[3];
 		} else {
-		    const u32x2 tt = *reinterpret_cast<const u32x2 *>(tail + i0);
+		    const u32x2 tt = *reinterpret_cast<const u32x2 *>(rec + SORA_REC_TAIL_AT(i0));
 		    tq[0] = tt[0]; tq[1] = tt[1];
 		}
 	    }

@@ -54,7 +54,7 @@ constexpr uint64_t kOffTileEnd = kOffStats + aligned((uint64_t) kMaxGroups * SOR
 constexpr uint64_t kTileSlots = kMaxSamples / 7808 + 16;	/* no scan kernel's tile is shorter */
 constexpr uint64_t kScratchUsed = kOffTileEnd + aligned(kTileSlots * 4);
 static_assert(kScratchUsed <= SORA_NOALLOC_SCRATCH_BYTES, "the lists do not fit the array");
-static_assert((kRecSlots & 15) == 0, "record regions are whole 16-record groups");
+static_assert(kRecSlots % SORA_REC_UNIT == 0, "record regions are whole units");
 
 } /* namespace */
 
@@ -170,7 +170,7 @@ sora_adsb_decode_noalloc(int device, void *stream_, const void *d_iq, size_t nby
      * slots suffice (one region always does) */
     const auto region_slots = [&](uint32_t g) {
 	const uint64_t tiles = (n_tiles + g - 1) / g;
-	return (uint32_t) ((tiles * tile_pos / 2 + 8 + 15) & ~15ull);
+	return (uint32_t) ((tiles * tile_pos / 2 + 8 + SORA_REC_UNIT - 1) & ~(uint64_t) (SORA_REC_UNIT - 1));
     };
     while (groups > 1 && (uint64_t) groups * region_slots(groups) > kRecSlots)
 	groups--;
@@ -186,8 +186,7 @@ sora_adsb_decode_noalloc(int device, void *stream_, const void *d_iq, size_t nby
     a.encoding = encoding;
     a.emit_all = emit_mode == SORA_EMIT_CANDIDATES;
     a.correct = (options & SORA_OPT_CORRECT_SINGLE_BIT) != 0;
-    a.key = reinterpret_cast<uint32_t *>(base + kOffRec);
-    a.tail = reinterpret_cast<uint8_t *>(a.key + kRecSlots);
+    a.rec = base + kOffRec;
     a.tile_end = reinterpret_cast<uint32_t *>(base + kOffTileEnd);
     a.sq = reinterpret_cast<uint64_t *>(base + kOffSq);
     a.sq_bits = reinterpret_cast<uint32_t *>(base + kOffSqBits);
@@ -207,8 +206,7 @@ sora_adsb_decode_noalloc(int device, void *stream_, const void *d_iq, size_t nby
     r.encoding = encoding;
     r.emit_all = a.emit_all;
     r.groups = groups;
-    r.key = a.key;
-    r.tail = a.tail;
+    r.rec = a.rec;
     r.tile_end = a.tile_end;
     r.n_tiles = n_tiles;
     r.tile_pos = tile_pos;

@@ -320,7 +320,7 @@ def test_overflow_reruns_a_streamed_block():
     want = [c for c in ob.scan(raw) if c["accepted"]]
     with AdsbContext(120000 + 239, max_candidates=16, max_squitters=16, max_frames=16) as ctx:
         got = frames_as_dicts(np.concatenate(list(ctx.stream(raw, ENC_UC8, 120000))))
-        assert ctx.list_regrows() >= 2
+        assert ctx.list_regrows() >= 1      # (a record list is one 256-record unit at least)
     assert_same_frames(got, want)
     want = ob.scan(raw)
     with AdsbContext(120000 + 239, emit_mode=EMIT_CANDIDATES, max_candidates=16,
