@@ -236,6 +236,8 @@ def run_archive(args, json_fd):
         scan_ms.append(prev[1].ctx.last_scan_ms())
 
     def fence():
+        for d in decs:                 # frame lists still on their way into the
+            d.wait_frames()            # node's shared segment (sharded.py)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -363,7 +365,7 @@ def main():
     # archive of recordings is worked through).  Every step still does all of
     # its work inside the timed region.
     streams, rstreams, ctxs, decs = [], [], [], []
-    two_stream = args.schedule == "two-stream" and args.inflight == 2
+    two_stream = args.schedule == "two-stream" and args.inflight >= 2
     if two_stream:
         # the scans of all captures on one stream, in the order they are begun;
         # what follows a scan on the other (by default at high priority: its short
@@ -424,6 +426,22 @@ def main():
         wait for it.  (--inflight 3 is the older schedule that moves the N>1
         exchange under the next scan.)"""
         n_dec, n = len(decs), 0
+        if two_stream:
+            # scans back to back on the one scan stream; the host stays n_dec - 1
+            # captures ahead of the frames it waits for (with two decoders it has
+            # what is left of a scan behind the previous resolve to queue the next
+            # scan in; a short shard leaves it too little, a third decoder a step more)
+            pending = []
+            for i in range(k):
+                d = decs[i % n_dec]
+                timed("begin", d.begin, *job)
+                timed("exchange", d.exchange)
+                pending.append(d)
+                if len(pending) == n_dec:
+                    n = finish(pending.pop(0))
+            while pending:
+                n = finish(pending.pop(0))
+            return n
         if n_dec >= 3:
             scanned, resolved = {}, {}
             for i in range(k + 2):
