@@ -46,6 +46,7 @@ struct sora_adsb_ctx {
     uint64_t *d_rec, *d_sq, *d_acc, *d_acc_flat, *d_first_seen, *d_stats;
     uint32_t *d_known_bits;
     uint32_t *d_sq_bits;	/* sora_scan_args::sq_bits: four words per squitter slot */
+    double *d_sq_sum;		/* sora_scan_args::sq_sum */
     uint64_t *d_acc_offset, *d_sq_offset;
     uint32_t *d_rec_count, *d_sq_count, *d_acc_count;
     uint32_t *d_tile_end;	/* sora_scan_args::tile_end: one word per tile of a chunk */
@@ -223,8 +224,10 @@ free_lists(sora_adsb_ctx *ctx) {
     (void) hipFree(ctx->d_rec);
     (void) hipFree(ctx->d_sq);
     (void) hipFree(ctx->d_sq_bits);
+    (void) hipFree(ctx->d_sq_sum);
     ctx->d_rec = ctx->d_sq = nullptr;
     ctx->d_sq_bits = nullptr;
+    ctx->d_sq_sum = nullptr;
     free_resolve_lists(ctx);
 }
 
@@ -245,6 +248,8 @@ bind_lists(sora_adsb_ctx *ctx) {
     a.tile_end = ctx->d_tile_end;
     a.sq = ctx->d_sq;
     a.sq_bits = ctx->d_sq_bits;
+    /* the sc16 scan kernel sums its squitters' amplitudes itself */
+    a.sq_sum = a.encoding == SORA_ENC_SC16? ctx->d_sq_sum : nullptr;
     a.rec_cap = share(ctx->rec_total, groups) & ~(SORA_REC_UNIT - 1);	/* >= a unit: sora_adsb_scan */
     a.sq_cap = share(ctx->sq_total, groups);
     r.rec = a.rec;
@@ -252,6 +257,7 @@ bind_lists(sora_adsb_ctx *ctx) {
     r.rec_cap = a.rec_cap;
     r.sq = ctx->d_sq;
     r.sq_bits = ctx->d_sq_bits;
+    r.sq_sum = a.sq_sum;
     r.sq_cap = a.sq_cap;
     r.acc = ctx->d_acc;
     r.acc_cap = share(ctx->acc_total, r.regions);
@@ -288,7 +294,8 @@ alloc_lists(sora_adsb_ctx *ctx) {
     hipError_t e;
     if ((e = list_alloc(&ctx->d_rec, ctx->rec_total + 8)) != hipSuccess ||
 	    (e = list_alloc(&ctx->d_sq, ctx->sq_total)) != hipSuccess ||
-	    (e = list_alloc(&ctx->d_sq_bits, 4 * ctx->sq_total)) != hipSuccess)
+	    (e = list_alloc(&ctx->d_sq_bits, 4 * ctx->sq_total)) != hipSuccess ||
+	    (e = list_alloc(&ctx->d_sq_sum, ctx->sq_total)) != hipSuccess)
 	return e;
     return alloc_resolve_lists(ctx);
 }

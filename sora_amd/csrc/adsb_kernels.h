@@ -28,6 +28,8 @@
 #define SORA_KNOWN_FOLD_WORDS	(1u << (SORA_KNOWN_FOLD_BITS - 5))	/* 16 KB */
 #define SORA_KNOWN_WORDS	(SORA_KNOWN_BITMAP_WORDS + SORA_KNOWN_FOLD_WORDS)
 
+#define SORA_AMP_SLOTS	32	/* see sora_scan_args::sq_sum */
+
 struct sora_scan_args {
     const uint8_t *iq;		/* device, 16-byte aligned */
     uint64_t n_samples;		/* samples in the chunk */
@@ -59,6 +61,12 @@ struct sora_scan_args {
      * corrected) squitter carries its index in this list where a reply's carries
      * its address */
     uint32_t *sq_bits;
+    /* [groups][sq_cap], or null: the amplitude sum of a clean squitter (the sum
+     * over its 112 samples that finalize hands out, plane-iq.c:72-73) where the
+     * scan kernel computes it itself, while the samples are still in the caches
+     * -- the sc16 kernel does, for up to SORA_AMP_SLOTS squitters per tile; an
+     * entry it did not get to is negative, and finalize sums that one's samples */
+    double *sq_sum;
     uint32_t rec_cap, sq_cap;	/* per-group capacities */
     uint32_t *rec_count;	/* [groups] records produced (may exceed cap) */
     uint32_t *sq_count;		/* [groups] */
@@ -91,6 +99,7 @@ struct sora_resolve_args {
     uint32_t rec_cap;
     const uint64_t *sq;
     const uint32_t *sq_bits;	/* see sora_scan_args */
+    const double *sq_sum;	/* see sora_scan_args; null: none were computed */
     const uint32_t *sq_count;
     uint32_t sq_cap;
     uint64_t *first_seen;	/* [1 << 24] smallest global position, or ~0

@@ -213,6 +213,69 @@ note_overflow(uint64_t *summary, int word, uint32_t count, uint32_t cap) {
 		(unsigned long long) count);
 }
 
+/* v of the lane `n` places up in this lane's row of 16, wrapping (row_ror) */
+template <int n> __device__ __forceinline__ uint32_t
+row_rotate(uint32_t v) {
+    return (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x120 + n, 0xf, 0xf, false);
+}
+
+__device__ __forceinline__ uint32_t
+row_xor(uint32_t v) {
+    v ^= row_rotate<8>(v);
+    v ^= row_rotate<4>(v);
+    v ^= row_rotate<2>(v);
+    v ^= row_rotate<1>(v);
+    return v;
+}
+
+__device__ __forceinline__ uint32_t
+row_sum(uint32_t v) {
+    v += row_rotate<8>(v);
+    v += row_rotate<4>(v);
+    v += row_rotate<2>(v);
+    v += row_rotate<1>(v);
+    return v;
+}
+
+__device__ __forceinline__ double
+row_sum(double v) {
+#define SORA_ROW_STEP(n) do { \
+	const uint32_t lo = row_rotate<n>((uint32_t) __double_as_longlong(v)); \
+	const uint32_t hi = row_rotate<n>((uint32_t) (__double_as_longlong(v) >> 32)); \
+	v += __longlong_as_double((long long) (((uint64_t) hi << 32) | lo)); \
+    } while (0)
+    SORA_ROW_STEP(8);
+    SORA_ROW_STEP(4);
+    SORA_ROW_STEP(2);
+    SORA_ROW_STEP(1);
+#undef SORA_ROW_STEP
+    return v;
+}
+
+typedef uint32_t u32x4_a2 __attribute__((ext_vector_type(4), aligned(2)));
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+
+/*
+ * This lane's share of a squitter's amplitude sum in sc16 (plane-iq.c:72-73 over
+ * the 112 samples behind the preamble): eight samples, a dword each; pairs
+ * (0,1) (2,3) ... are the two halves of a bit: the float sum of a pair,
+ * accumulated in double -- every term is an integer, so the order of the
+ * additions does not show.  row_sum() of it over the fourteen lanes that hold
+ * samples (the other two hold zeros) is the sum the frame carries.
+ */
+__device__ __forceinline__ double
+squitter_sum_wide(const u32x4 &s0, const u32x4 &s1) {
+    const uint32_t d[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+    double dsum = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) {
+	const float s = __fadd_rn(__uint_as_float(sora_mag_sc16(d[i])),
+		__uint_as_float(sora_mag_sc16(d[i + 1])));
+	dsum += (double) s;
+    }
+    return dsum;
+}
+
 template <bool kWide>
 __global__ void __launch_bounds__(tile_geom<kWide>::threads, tile_geom<kWide>::waves_per_simd)
 adsb_scan_kernel(sora_scan_args a) {
@@ -251,6 +314,9 @@ adsb_scan_kernel(sora_scan_args a) {
      * whose lanes are the later waves), read behind the barrier. */
     __shared__ uint32_t s_cum[kWaves + 1];
     __shared__ uint32_t s_sq_total;	/* clean squitters so far, all tiles */
+    /* sc16: where in the tile the squitters it added to the list lie (0xffff: a
+     * corrected one), for their amplitude sums (sora_scan_args::sq_sum) */
+    __shared__ uint16_t s_amp_q[kWide? SORA_AMP_SLOTS : 1];
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63, wave = tid >> 6;
@@ -267,6 +333,51 @@ adsb_scan_kernel(sora_scan_args a) {
     uint32_t n_rec = 0;			/* workgroup-uniform */
     if (tid == 0)
 	s_sq_total = 0;			/* visible behind the first tile's barriers */
+
+    /*
+     * sc16: the amplitude sums of a tile's clean squitters, one tile late.  The
+     * squitters phase 4 appended to the list while it worked on tile t (entries
+     * amp_k0 .. amp_k0 + amp_n of the list, positions amp_start + s_amp_q[]) are
+     * summed while tile t + 1 is loaded: sixteen lanes a squitter, fourteen of
+     * them 32 bytes each, out of the caches the tile has just come through, and
+     * issued together with the next tile's own loads, so that no round trip is
+     * added to the tile.  finalize then has nothing to read for these frames but
+     * their list entries (dense traffic: 448 bytes of samples per frame, 41 % of
+     * the capture a second time).
+     */
+    const bool amp_on = kWide && a.sq_sum != nullptr;
+    double *const sq_sum_out = amp_on? a.sq_sum + (uint64_t) group * a.sq_cap : nullptr;
+    uint32_t amp_k0 = 0, amp_n = 0, sq_seen = 0;	/* workgroup-uniform */
+    uint64_t amp_start = 0;
+    auto amp_issue = [&](u32x4 (&smp)[2][2], uint32_t (&entry)[2]) {
+#pragma unroll
+	for (int ps = 0; ps < 2; ps++) {
+	    const uint32_t slot = 16 * ps + (tid >> 4), sub = tid & 15;
+	    smp[ps][0] = smp[ps][1] = u32x4{0, 0, 0, 0};
+	    entry[ps] = ~0u;
+	    if (slot < amp_n) {
+		const uint32_t q = s_amp_q[slot];
+		if (q != 0xffffu && amp_k0 + slot < a.sq_cap) {
+		    entry[ps] = amp_k0 + slot;
+		    if (sub < 14) {
+			const uint8_t *src = a.iq + 4 * (amp_start + q + 16) + 32 * sub;
+			smp[ps][0] = *reinterpret_cast<const u32x4_a4 *>(src);
+			smp[ps][1] = *reinterpret_cast<const u32x4_a4 *>(src + 16);
+		    }
+		}
+	    }
+	}
+    };
+    auto amp_finish = [&](const u32x4 (&smp)[2][2], const uint32_t (&entry)[2]) {
+#pragma unroll
+	for (int ps = 0; ps < 2; ps++) {
+	    if (16u * ps >= amp_n)
+		break;				/* workgroup-uniform */
+	    const double total = row_sum(squitter_sum_wide(smp[ps][0], smp[ps][1]));
+	    if (entry[ps] != ~0u && (tid & 15) == 0)
+		sq_sum_out[entry[ps]] = total;
+	}
+    };
     uint32_t st_cand = 0, st_sq = 0, st_dirty = 0, st_fixed = 0;
 
     uint16_t *const s_big_queue = reinterpret_cast<uint16_t *>(s_m);
@@ -312,8 +423,18 @@ adsb_scan_kernel(sora_scan_args a) {
 
 	/* ---- phase 1: load, magnitude, LDS ---- */
 	{
+	    u32x4 amp_smp[2][2];
+	    uint32_t amp_entry[2];
+	    if constexpr (kWide) {
+		if (amp_n != 0)
+		    amp_issue(amp_smp, amp_entry);
+	    }
 	    u32x4 v[kLoads];
 	    load_tile(v, tile, t * 16);
+	    if constexpr (kWide) {
+		if (amp_n != 0)
+		    amp_finish(amp_smp, amp_entry);
+	    }
 	    STAMP_WAIT_VM();
 	    STAMP(0);			/* HBM latency of the tile's loads */
 #pragma unroll
@@ -500,6 +621,15 @@ adsb_scan_kernel(sora_scan_args a) {
 			sq_out[k] = sora_rec_make(kind, tile_start + q, payload);
 			sq_bits_out[k] = u32x4{c.bits[0], c.bits[1], c.bits[2], c.bits[3]};
 		    }
+		    if constexpr (kWide) {
+			if (amp_on) {
+			    if (k - sq_seen < (uint32_t) SORA_AMP_SLOTS)
+				s_amp_q[k - sq_seen] = kind == SORA_REC_KIND_SQUITTER?
+					(uint16_t) q : (uint16_t) 0xffffu;
+			    else if (k < a.sq_cap)
+				sq_sum_out[k] = -1.0;	/* finalize sums this one */
+			}
+		    }
 		    word = k & 0xffffffu;
 		}
 		/* key and tail (sora_scan_args) */
@@ -524,11 +654,29 @@ adsb_scan_kernel(sora_scan_args a) {
 	 * tables and the NU arrays: no barrier here unless the queue is in M. */
 	if (big)
 	    lds_barrier();
+	if constexpr (kWide) {
+	    /* (big: behind the barrier) what this tile added to the squitter list */
+	    const uint32_t now = s_sq_total;
+	    amp_k0 = sq_seen;
+	    amp_n = now - sq_seen < (uint32_t) SORA_AMP_SLOTS? now - sq_seen : SORA_AMP_SLOTS;
+	    amp_start = tile_start;
+	    sq_seen = now;
+	    if (!amp_on)
+		amp_n = 0;
+	}
 	STAMP(6);			/* candidates: extract, CRC, records */
     }
 
     /* per-workgroup results */
     lds_barrier();			/* the last tile's squitter appends */
+    if constexpr (kWide) {
+	if (amp_n != 0) {		/* ... and their sums */
+	    u32x4 amp_smp[2][2];
+	    uint32_t amp_entry[2];
+	    amp_issue(amp_smp, amp_entry);
+	    amp_finish(amp_smp, amp_entry);
+	}
+    }
     if (tid == 0) {
 	a.rec_count[group] = n_rec;
 	a.sq_count[group] = s_sq_total;
@@ -1643,45 +1791,6 @@ load_given_bits(const sora_resolve_args &a, uint64_t r, uint32_t sub) {
     return mine;
 }
 
-/* v of the lane `n` places up in this lane's row of 16, wrapping (row_ror) */
-template <int n> __device__ __forceinline__ uint32_t
-row_rotate(uint32_t v) {
-    return (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x120 + n, 0xf, 0xf, false);
-}
-
-__device__ __forceinline__ uint32_t
-row_xor(uint32_t v) {
-    v ^= row_rotate<8>(v);
-    v ^= row_rotate<4>(v);
-    v ^= row_rotate<2>(v);
-    v ^= row_rotate<1>(v);
-    return v;
-}
-
-__device__ __forceinline__ uint32_t
-row_sum(uint32_t v) {
-    v += row_rotate<8>(v);
-    v += row_rotate<4>(v);
-    v += row_rotate<2>(v);
-    v += row_rotate<1>(v);
-    return v;
-}
-
-__device__ __forceinline__ double
-row_sum(double v) {
-#define SORA_ROW_STEP(n) do { \
-	const uint32_t lo = row_rotate<n>((uint32_t) __double_as_longlong(v)); \
-	const uint32_t hi = row_rotate<n>((uint32_t) (__double_as_longlong(v) >> 32)); \
-	v += __longlong_as_double((long long) (((uint64_t) hi << 32) | lo)); \
-    } while (0)
-    SORA_ROW_STEP(8);
-    SORA_ROW_STEP(4);
-    SORA_ROW_STEP(2);
-    SORA_ROW_STEP(1);
-#undef SORA_ROW_STEP
-    return v;
-}
-
 /* frame f of the list, in the form the context hands out (plane.c:461-480 for
  * the fields derived from the bits) */
 template <bool kWire> __device__ __forceinline__ void
@@ -1833,9 +1942,6 @@ row_shift_right(uint32_t v) {
     return (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x110 + n, 0xf, 0xf, true);
 }
 
-typedef uint32_t u32x4_a2 __attribute__((ext_vector_type(4), aligned(2)));
-typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
-
 /*
  * The clean squitters of a batch -- nearly every frame of a capture -- need no
  * slicing and no CRC here: the scan kept their bits (sora_scan_args::sq_bits)
@@ -1854,6 +1960,27 @@ finalize_squitters(const sora_resolve_args &a, uint64_t batch, uint32_t cnt, uin
     constexpr uint32_t kActive = kWide? 14 : 7;		/* lanes of a frame that load */
     const uint32_t sub = lane % kLanes, grp = lane / kLanes;
 
+    if constexpr (kWide) {
+	/* the scan kernel has summed most of them already (sora_scan_args::sq_sum):
+	 * a lane a frame, its list entry and nothing else */
+	if (a.sq_sum != nullptr) {
+	    const bool cand = lane < cnt && ((fast >> lane) & 1) != 0;
+	    double total = -1.0;
+	    uint64_t entry = 0;
+	    if (cand) {
+		entry = squitter_entry(a, mine);
+		total = a.sq_sum[entry];
+	    }
+	    const bool ready = cand && total >= 0.0;
+	    if (ready) {
+		const u32x4 w = *reinterpret_cast<const u32x4 *>(a.sq_bits + 4 * entry);
+		const uint32_t bits[4] = {w[0], w[1], w[2], w[3]};
+		store_frame<kWire>(a, batch + lane, mine, bits, 0u, -1, 0u,
+			total * (1.0 / 2147483648.0), (uint64_t) total);
+	    }
+	    fast &= ~__ballot(ready);
+	}
+    }
     for (uint32_t j = 0; j < cnt; j += kFrames) {
 	if (((fast >> j) & ((1ull << kFrames) - 1)) == 0)
 	    continue;					/* wave-uniform */
@@ -1884,16 +2011,7 @@ finalize_squitters(const sora_resolve_args &a, uint64_t batch, uint32_t cnt, uin
 	uint64_t amp;
 	bool writer;
 	if constexpr (kWide) {
-	    /* a dword is a sample; pairs (0,1) (2,3) ...: the float sum of a pair,
-	     * accumulated in double, as finalize_four does (every term an integer) */
-	    double dsum = 0;
-#pragma unroll
-	    for (int i = 0; i < 8; i += 2) {
-		const float s = __fadd_rn(__uint_as_float(sora_mag_sc16(d[i])),
-			__uint_as_float(sora_mag_sc16(d[i + 1])));
-		dsum += (double) s;
-	    }
-	    const double total = row_sum(dsum);
+	    const double total = row_sum(squitter_sum_wide(s0, s1));
 	    a56 = total * (1.0 / 2147483648.0);
 	    amp = (uint64_t) total;
 	    writer = sub == 0;
