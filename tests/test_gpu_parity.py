@@ -576,6 +576,48 @@ def test_correction_sc16_every_bit():
     assert_same_frames(got, want)
 
 
+@pytest.mark.parametrize("correct", [False, True])
+def test_sc16_more_squitters_in_a_tile_than_the_scan_sums(correct):
+    """The sc16 scan kernel sums the amplitudes of up to SORA_AMP_SLOTS (32) clean
+    squitters per 7936-position tile itself and leaves the others to finalize
+    (sora_scan_args::sq_sum): short squitters 130 samples apart are 61 to a tile,
+    over four tiles, every fifth with a flipped bit (a corrected squitter takes a
+    slot but is summed by finalize), every amplitude against the oracle's; then
+    the same capture through a context whose lists start too small (regrow)."""
+    df11 = synth.hex_to_bits("5D4840D6F8740F")
+    klm = synth.hex_to_bits("8D4840D6202CC371C32CE0576098")
+    rows, pos = [], 300
+    for i in range(240):
+        w = np.array(df11, dtype=np.uint32).copy()
+        if i % 5 == 4:
+            b = 5 + (7 * i) % 51
+            w[b >> 5] ^= np.uint32(0x80000000 >> (b & 31))
+        rows.append((pos, w, 3000 + 37 * (i % 100), 0, 56))
+        pos += 130
+    for i in range(20):                                  # and a sparse stretch of long ones
+        rows.append((pos, np.array(klm, dtype=np.uint32), 5000 + 211 * i, 0, 112))
+        pos += 2500
+    raw = synth.fill_host(pos + 600, ENC_SC16, 11, synth.frame_table(rows)).tobytes()
+    n = len(raw) // 4
+    want = ob.scan(raw, ENC_SC16, correct=correct)
+    clean = [c for c in want if c["df"] in (11, 17) and c["syndrome"] == 0
+             and c["corrected_bit"] < 0]
+    per_tile = np.bincount([c["position"] // 7936 for c in clean])
+    assert per_tile.max() > 40 and (per_tile > 32).sum() >= 3
+    if correct:
+        assert sum(c["corrected_bit"] >= 0 for c in want) >= 40
+    for emit in (EMIT_CANDIDATES, EMIT_ACCEPTED):
+        sel = want if emit == EMIT_CANDIDATES else [c for c in want if c["accepted"]]
+        for small in (False, True):
+            kw = (dict(max_candidates=2048, max_squitters=64, max_frames=64) if small else
+                  dict(max_candidates=n // 2, max_squitters=n // 2))
+            with AdsbContext(n, emit_mode=emit, correct_single_bit=correct, **kw) as ctx:
+                ctx.submit_host(raw, ENC_SC16)
+                got = frames_as_dicts(ctx.collect())
+                assert small == (ctx.list_regrows() > 0)
+            assert_same_frames(got, sel)
+
+
 # ---- streaming ingest (SURVEY.md section 8 f.4): sora_adsb_stream_*
 
 @pytest.mark.parametrize("enc,block", [(ENC_UC8, 1024), (ENC_UC8, 50000), (ENC_UC8, 400000),
