@@ -63,8 +63,8 @@ struct sora_scan_args {
     uint32_t *sq_bits;
     /* [groups][sq_cap], or null: the amplitude sum of a clean squitter (the sum
      * over its 112 samples that finalize hands out, plane-iq.c:72-73) where the
-     * scan kernel computes it itself, while the samples are still in the caches
-     * -- the sc16 kernel does, for up to SORA_AMP_SLOTS squitters per tile; an
+     * scan kernel computes it itself, under its own loads and arithmetic -- the
+     * sc16 kernel does, for up to SORA_AMP_SLOTS squitters per tile; an
      * entry it did not get to is negative, and finalize sums that one's samples */
     double *sq_sum;
     uint32_t rec_cap, sq_cap;	/* per-group capacities */

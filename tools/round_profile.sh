@@ -34,6 +34,10 @@ side shard900M_events --samples 9e8 --steps 100 --schedule events
 side shard900M_force_collective_events --samples 9e8 --steps 100 --force-collective --schedule events
 side sc16_dense --encoding sc16 --samples 3.6e9
 side archive8 --archive 8
+# where a short shard's step goes on the N>1 path and locally (HIP events)
+timeout -k 10 200 python tools/shard_timeline.py 9e8 collective 6 300 > "$O/shard900M_timeline_collective.txt" 2> /dev/null
+timeout -k 10 200 python tools/shard_timeline.py 9e8 local 6 300 > "$O/shard900M_timeline_local.txt" 2> /dev/null
+tail -1 "$O/shard900M_timeline_collective.txt"
 # the same default command under rocprofv3 (what roofline.kernel_ms must agree with)
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof2" -- \
     python3 bench.py --steps 30 --warmup 5 --no-cpu \
@@ -61,7 +65,13 @@ timeout -s KILL 120 rocprofv3 --pmc GRBM_GUI_ACTIVE GRBM_COUNT --kernel-trace --
 KERNEL=$(python3 -c "import json,sys; print(json.load(open('$O/bench_default.json'))['roofline']['kernel'].split(' ')[0])")
 python3 tools/hbm_traffic.py "$O/pmc_fetch" "$O/pmc_write" uc8 14400000000 "$KERNEL" > "$O/hbm_traffic.json"
 cat "$O/hbm_traffic.json"
-for d in pmc_fetch pmc_write pmc_sq pmc_grbm; do
+# the same two passes over the dense sc16 side workload
+B16="$B --encoding sc16 --samples 3.6e9"
+timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc16_fetch" -- $B16 > /dev/null 2> "$O/pmc16_fetch.err"
+timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc16_write" -- $B16 > /dev/null 2> "$O/pmc16_write.err"
+python3 tools/hbm_traffic.py "$O/pmc16_fetch" "$O/pmc16_write" sc16 14400000000 "adsb_scan_kernel<true>" > "$O/hbm_traffic_sc16.json"
+cat "$O/hbm_traffic_sc16.json"
+for d in pmc_fetch pmc_write pmc_sq pmc_grbm pmc16_fetch pmc16_write; do
     cat "$O"/$d/*/*counter_collection.csv | grep -E "Counter_Name|adsb_scan|filter_kernel|finalize_kernel" > "$O/$d.csv" || true
     rm -rf "$O/$d"
 done
