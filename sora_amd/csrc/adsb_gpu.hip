@@ -38,6 +38,7 @@ struct sora_adsb_ctx {
     uint32_t max_groups;	/* workgroups the scan kernel may use */
     uint32_t scan_variant;	/* 8-bit scan kernel: 1 magnitudes in registers (default), 0 through LDS */
     uint32_t scan_rounds, scan_min_tiles;	/* see sora_adsb_create() */
+    uint32_t scan_sums;		/* 0: no scan kernel sums amplitudes (SORA_ADSB_SCAN_SUMS) */
     uint32_t max_regions;	/* accepted regions (sora_filter_max_regions) */
     uint32_t cus;
     uint64_t rec_total, sq_total, acc_total, frames_cap;
@@ -249,7 +250,7 @@ bind_lists(sora_adsb_ctx *ctx) {
     a.sq = ctx->d_sq;
     a.sq_bits = ctx->d_sq_bits;
     /* the sc16 scan kernel sums its squitters' amplitudes itself */
-    a.sq_sum = a.encoding == SORA_ENC_SC16? ctx->d_sq_sum : nullptr;
+    a.sq_sum = a.encoding == SORA_ENC_SC16 && ctx->scan_sums != 0? ctx->d_sq_sum : nullptr;
     a.rec_cap = share(ctx->rec_total, groups) & ~(SORA_REC_UNIT - 1);	/* >= a unit: sora_adsb_scan */
     a.sq_cap = share(ctx->sq_total, groups);
     r.rec = a.rec;
@@ -472,6 +473,7 @@ sora_adsb_create(sora_adsb_ctx **out, int device, const sora_adsb_config *cfg) {
     ctx->scan_variant = env_number("SORA_ADSB_SCAN_VARIANT", 1, 0, 1);
     ctx->scan_rounds = env_number("SORA_ADSB_SCAN_ROUNDS", kScanRounds, 1, 64);
     ctx->scan_min_tiles = env_number("SORA_ADSB_SCAN_MIN_TILES", kMinTiles, 1, 1 << 20);
+    ctx->scan_sums = env_number("SORA_ADSB_SCAN_SUMS", 1, 0, 1);
     ctx->max_groups = ctx->cus * 8 * ctx->scan_rounds;
     ctx->max_regions = sora_filter_max_regions(ctx->max_groups);
 

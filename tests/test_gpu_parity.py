@@ -618,6 +618,59 @@ def test_sc16_more_squitters_in_a_tile_than_the_scan_sums(correct):
             assert_same_frames(got, sel)
 
 
+def test_config4_size_properties(monkeypatch):
+    """BASELINE configs[3] at 120 M samples (480 MB of sc16, dense overlapping
+    traffic, a fifth of the frames with a flipped bit, correction on): sorted
+    output, idempotence, the same frames byte for byte whether the scan kernel or
+    finalize sums a squitter's amplitude (SORA_ADSB_SCAN_SUMS), a 2 M-sample
+    window in the middle against the oracle, ragged haloed chunks equal to the
+    whole."""
+    import torch
+    p = synth.default_params(4)
+    fr = synth.make_frames(p)
+    n = p.n_samples
+    d = torch.empty(4 * n, dtype=torch.uint8, device="cuda")
+    synth.fill_device(d.data_ptr(), n, ENC_SC16, p.seed, fr)
+    kw = dict(correct_single_bit=True, max_candidates=n // 8, max_squitters=n // 128,
+              max_frames=n // 128)
+    with AdsbContext(n, **kw) as ctx:
+        ctx.submit_device(d, 4 * n, ENC_SC16)
+        a = ctx.collect()
+        ctx.reset()
+        ctx.submit_device(d, 4 * n, ENC_SC16)
+        b = ctx.collect()
+        assert ctx.scan_kernel_name(ENC_SC16) == "adsb_scan_kernel<true>"
+    assert a.tobytes() == b.tobytes()                       # idempotent
+    pos = a["position"].astype(np.int64)
+    assert np.all(np.diff(pos) > 0) and len(a) > n // 1000
+    assert (a["corrected_bit"] >= 0).sum() > len(a) // 20
+    monkeypatch.setenv("SORA_ADSB_SCAN_SUMS", "0")
+    with AdsbContext(n, **kw) as ctx:
+        ctx.submit_device(d, 4 * n, ENC_SC16)
+        assert ctx.collect().tobytes() == a.tobytes()       # finalize's sums are the scan's
+    monkeypatch.delenv("SORA_ADSB_SCAN_SUMS")
+    lo, m = 60000000, 2000000
+    raw = d[4 * lo:4 * (lo + m)].cpu().numpy().tobytes()
+    ps = ob.PlaneSet()
+    for f in a[pos < lo]:                                   # addresses known so far
+        if int(f["flags"]) & sora_amd.FRAME_SQUITTER:
+            ps.parse(sora_amd.bits_to_string(f["bits"]))
+    want = [c for c in ob.scan(raw, ENC_SC16, base_position=lo, plane_set=ps, correct=True)
+            if c["accepted"]]
+    assert len(want) > 1000
+    assert_same_frames(frames_as_dicts(a[(pos >= lo) & (pos < lo + m - 239)]), want)
+    cuts = np.linspace(0, n, 6).astype(np.int64) // 8 * 8
+    cuts[1:-1] += np.array([8, 64, 1000, 7936])
+    out = []
+    with AdsbContext(int(np.diff(cuts).max()) + 239, **kw) as ctx:
+        for s_, e in zip(cuts[:-1], cuts[1:]):
+            end = int(e) if e == cuts[-1] else int(e) + 239
+            ctx.submit_device(d.data_ptr() + 4 * int(s_), 4 * (end - int(s_)), ENC_SC16,
+                              base_position=int(s_), n_owned=int(e - s_))
+            out.append(ctx.collect())
+    assert np.concatenate(out).tobytes() == a.tobytes()
+
+
 # ---- streaming ingest (SURVEY.md section 8 f.4): sora_adsb_stream_*
 
 @pytest.mark.parametrize("enc,block", [(ENC_UC8, 1024), (ENC_UC8, 50000), (ENC_UC8, 400000),
