@@ -85,6 +85,7 @@ struct sora_adsb_ctx {
 	uint64_t base_position, n_owned;
     } last;
     uint32_t regrows;		/* re-runs so far (sora_adsb_regrow_count) */
+    size_t last_collected;	/* frames the last collect copied to the host */
     uint64_t *d_export;		/* one record per address first seen in this scan */
     uint64_t export_cap;
     sora_scan_args scan;
@@ -172,6 +173,7 @@ use_resolve_stream(sora_adsb_ctx *ctx) {
 constexpr uint32_t kScanRounds = 32;	/* rounds of scan workgroups per CU */
 constexpr uint64_t kSummaryAlloc = 32;	/* words behind d_summary: zeroed 256 bytes at a time */
 constexpr uint32_t kMinTiles = 8;	/* tiles per workgroup, at least */
+constexpr size_t kAheadBytes = 2u << 20;	/* collect: frame lists up to this are sent ahead of their count */
 
 uint32_t
 env_number(const char *name, uint32_t fallback, long lo, long hi) {
@@ -980,9 +982,28 @@ collect_common(sora_adsb_ctx *ctx, void *dst, size_t cap, size_t *n,
 	return fail(ctx, SORA_ERR_STATE, "collect without a resolve");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, use_resolve_stream(ctx));
+    const size_t frame_bytes = wire? sizeof(sora_adsb_wire_frame) : sizeof(sora_adsb_frame);
     /* the common case in one small copy: every list held */
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_summary, ctx->d_summary,
 	    SORA_SUM_WORDS * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->rstream));
+    /* ... and, to the host, in one wait: as many frames as the last collect of
+     * this context found and a thirty-second more are on their way before the
+     * count is known (captures that follow one another resemble one another; a
+     * wait costs the host 10 us, what 0.5 MB on the link cost: short lists
+     * only, a long one is bound by the link and pays for every byte too many);
+     * what is then missing follows below */
+    size_t ahead = 0;
+    if (kind == hipMemcpyDeviceToHost && ctx->last_collected > 0 &&
+	    ctx->last_collected * frame_bytes <= kAheadBytes) {
+	ahead = ctx->last_collected + ctx->last_collected / 32 + 64;
+	if (ahead > cap)
+	    ahead = cap;
+	if (ahead > ctx->frames_cap)
+	    ahead = (size_t) ctx->frames_cap;
+	if (ahead > 0)
+	    HIP_TRY(ctx, hipMemcpyAsync(dst, ctx->d_frames, ahead * frame_bytes, kind,
+		    ctx->rstream));
+    }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->rstream));
     if (ctx->h_summary[SORA_SUM_REC_OVER] != 0 || ctx->h_summary[SORA_SUM_SQ_OVER] != 0 ||
 	    ctx->h_summary[SORA_SUM_ACC_OVER] != 0 ||
@@ -993,15 +1014,19 @@ collect_common(sora_adsb_ctx *ctx, void *dst, size_t cap, size_t *n,
 	    return rc;
 	if (overflow)
 	    return SORA_ERR_OVERFLOW;	/* ensure_complete has said which list and why */
+	ahead = 0;			/* the frames are new ones, in a new list */
     } else {
 	ctx->h_total[1] = ctx->h_summary[SORA_SUM_FRAMES];
     }
     const uint64_t total = ctx->h_total[1];
     *n = (size_t) total;
     const size_t take = total < cap? (size_t) total : cap;
-    if (take > 0) {
-	HIP_TRY(ctx, hipMemcpyAsync(dst, ctx->d_frames, take * (wire?
-		sizeof(sora_adsb_wire_frame) : sizeof(sora_adsb_frame)), kind, ctx->rstream));
+    if (kind == hipMemcpyDeviceToHost)
+	ctx->last_collected = take;
+    if (take > ahead) {
+	HIP_TRY(ctx, hipMemcpyAsync(static_cast<uint8_t *>(dst) + ahead * frame_bytes,
+		reinterpret_cast<const uint8_t *>(ctx->d_frames) + ahead * frame_bytes,
+		(take - ahead) * frame_bytes, kind, ctx->rstream));
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->rstream));
     }
     return SORA_OK;

@@ -755,6 +755,37 @@ def test_wire_frames_unpack_to_the_same_frames(enc):
         assert len(ref) > 100 and ref["amplitude_56"].max() > 56 * 0.5
 
 
+@pytest.mark.parametrize("wire", [False, True])
+def test_collect_behind_collects_of_other_sizes(wire):
+    """A collect to the host sends as many frames as the context's last one found
+    (and a few more) on their way before it knows the count: captures with more
+    frames than the one before, with fewer, with none, a second collect of the
+    same capture and a destination smaller than the list all hand out what a
+    fresh context does."""
+    rng = np.random.default_rng(77)
+    sizes = [200000, 450000, 460000, 3000, 900000, 100000]
+    raws = [rng.integers(0, 256, size=2 * n, dtype=np.uint8).tobytes() for n in sizes]
+    raws[3] = bytes(2 * sizes[3])                           # silence: no frame at all
+    kw = dict(emit_mode=EMIT_CANDIDATES, wire_frames=wire)
+    fresh = []
+    for raw, n in zip(raws, sizes):
+        with AdsbContext(n, max_candidates=n // 2 + 1024, **kw) as ctx:
+            ctx.submit_host(raw, ENC_UC8)
+            fresh.append(ctx.collect())
+    assert len(fresh[3]) == 0 and len(fresh[4]) > 1.9 * len(fresh[1]) > 3.8 * len(fresh[0])
+    n = max(sizes)
+    with AdsbContext(n, max_candidates=n // 2 + 1024, **kw) as ctx:
+        for raw, want in zip(raws, fresh):
+            ctx.reset()
+            ctx.submit_host(raw, ENC_UC8)
+            assert ctx.collect().tobytes() == want.tobytes()
+            assert ctx.collect().tobytes() == want.tobytes()
+            few = np.zeros(min(50, len(want)), dtype=want.dtype)
+            assert ctx.collect_into(few) == len(want)
+            assert few.tobytes() == want[:len(few)].tobytes()
+            assert ctx.collect().tobytes() == want.tobytes()
+
+
 def test_stream_source_failure_is_not_end_of_stream():
     """An exception inside the read callback (ctypes would swallow it and the
     library would see a short read = end of stream) reaches the caller."""
