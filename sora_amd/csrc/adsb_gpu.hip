@@ -1021,7 +1021,7 @@ collect_common(sora_adsb_ctx *ctx, void *dst, size_t cap, size_t *n,
     const uint64_t total = ctx->h_total[1];
     *n = (size_t) total;
     const size_t take = total < cap? (size_t) total : cap;
-    if (kind == hipMemcpyDeviceToHost)
+    if (kind == hipMemcpyDeviceToHost && cap > 0)	/* (cap 0 only asks for the count) */
 	ctx->last_collected = take;
     if (take > ahead) {
 	HIP_TRY(ctx, hipMemcpyAsync(static_cast<uint8_t *>(dst) + ahead * frame_bytes,
