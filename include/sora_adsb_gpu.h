@@ -276,6 +276,9 @@ int sora_adsb_stream_end(sora_adsb_ctx *ctx);
  * buffer (sora_adsb_collect_device).  *n is the number available; at most
  * cap are written.  A device list that overflowed is grown and the chunk run
  * again first (SORA_OPT_FIXED_LISTS: SORA_ERR_OVERFLOW instead).
+ * What `out` holds behind the first min(*n, cap) frames is unspecified: to the
+ * host a short list travels before its count is known, sized by the context's
+ * last collect, and may have been longer than the list turned out to be.
  */
 int sora_adsb_collect(sora_adsb_ctx *ctx, struct sora_adsb_frame *out,
 	size_t cap, size_t *n);
